@@ -1,0 +1,463 @@
+"""CPU oracle for the show-attend-tell caption-decoding path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference's batched inference path.  It is
+the *checker* for the HIP engine: only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it.  Nothing under `image_caption_amd/`
+imports it, and the product path raises when the HIP library is missing instead of
+falling back to this code.
+
+Why a restatement: the reference is Python on TensorFlow 2.3 eager
+(`requirements.txt:1`), TensorFlow is not installed in the build container and no
+reference file travels to the GPU box.  The arithmetic therefore follows the
+reference source line by line plus the public contracts of the TF 2.3 / Keras ops it
+calls (stated in each docstring).  Operation ORDER is preserved wherever it changes
+fp32 rounding (two-step length penalty, `(x.K + h.R) + b` in the LSTM cell,
+`fm*probs + (1-fm)*row` masking, un-hoisted `W1(features)`).
+
+Pinning status
+  * beam search step / back-tracking: PINNED by the reference's own golden vectors
+    (`beam_search/beam_search_test.py:36-59` and `:61-108`), see
+    `tests/test_oracle_golden.py`.
+  * encoder, embedding, init-state, attention, LSTM step, logits, end-to-end loop:
+    PARITY UNPINNED - the reference holds no test, fixture or golden vector for
+    them.  They are cross-checked against independent torch-CPU primitives
+    (`torch.nn.functional.linear/embedding/softmax`, `torch.nn.LSTMCell`) in
+    `tests/test_oracle_crosscheck.py`, which guards the restatement against
+    transcription slips but is not a reference-derived pin.
+
+All functions take and return numpy arrays.  `dtype` defaults to float32 (the
+reference's `tf.float32`); passing float64 weights/inputs gives a high-precision
+"truth" run used by the tests to measure top-k margins.
+"""
+
+from __future__ import annotations
+
+from collections import namedtuple
+
+import numpy as np
+
+F32_MIN = np.float32(np.finfo(np.float32).min)  # tf.float32.min = -3.4028235e38
+
+
+# ----------------------------------------------------------------------------------
+# Keras layer contracts
+# ----------------------------------------------------------------------------------
+
+def dense(x, kernel, bias):
+    """`tf.keras.layers.Dense` without activation: `x . kernel[in,out] + bias`,
+    applied over the last axis for rank-3 inputs."""
+    return np.matmul(x, kernel) + bias
+
+
+def sigmoid(x):
+    """`tf.nn.sigmoid` = 1 / (1 + exp(-x))."""
+    one = x.dtype.type(1)
+    return one / (one + np.exp(-x))
+
+
+def softmax(x, axis):
+    """`tf.nn.softmax`: exp(x - max) / sum(exp(x - max)) along `axis`."""
+    m = np.max(x, axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / np.sum(e, axis=axis, keepdims=True)
+
+
+def log_softmax(x):
+    """`tf.nn.log_softmax` over the last axis: `(x - max) - log(sum(exp(x - max)))`."""
+    shifted = x - np.max(x, axis=-1, keepdims=True)
+    return shifted - np.log(np.sum(np.exp(shifted), axis=-1, keepdims=True))
+
+
+# ----------------------------------------------------------------------------------
+# encoder / embedding / init state / attention / decoder step
+# ----------------------------------------------------------------------------------
+
+def mlp_encoder(x, enc_kernel, enc_bias):
+    """`MlpEncoder.call` (`encoder/mlp_encoder.py:16-21`): Dense(F->D), ReLU, dropout
+    (identity with `training=False`).  x[B,L,F] -> features[B,L,D]."""
+    return np.maximum(dense(x, enc_kernel, enc_bias), x.dtype.type(0))
+
+
+def embedding_lookup(table, ids):
+    """`EmbeddingLayer.call` (`decoder/embedding.py:9-10`): row gather."""
+    return table[np.asarray(ids).reshape(-1)]
+
+
+def feature_proj_state(features, kernel, bias, mask=None):
+    """`FeatureProjState.__call__` (`decoder/init_state.py:10-36`).
+
+    Unmasked: Dense(mean over L).  Masked: the masked SUM over L (never divided by
+    the mask count, `:17-32`), zero where the mask row sums to zero."""
+    if mask is None:
+        pooled = np.mean(features, axis=-2, dtype=features.dtype)
+    else:
+        msum = np.sum(features * mask[..., None], axis=-2, dtype=features.dtype)
+        cnt = np.sum(mask, axis=-1, keepdims=True)
+        pooled = np.where(cnt == 0, np.zeros_like(msum), msum)
+    return dense(pooled, kernel, bias)
+
+
+def bahdanau_attention(features, hidden, p, bias=None):
+    """`BahdanauAttention.call` (`attention/attention.py:40-65`).
+
+    score = V(tanh(W1(features) + W2(hidden)[:,None,:])) (+ bias[:, :, None]);
+    weights = softmax over the L axis; context = sum_L weights * features.
+    Returns (context[N,D], weights[N,L,1])."""
+    w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"])            # [N,L,U]
+    w2h = dense(hidden[:, None, :], p["att_W2_kernel"], p["att_W2_bias"])  # [N,1,U]
+    act = np.tanh(w1f + w2h)
+    score = dense(act, p["att_V_kernel"], p["att_V_bias"])                 # [N,L,1]
+    if bias is not None:
+        score = score + bias[..., None]
+    weights = softmax(score, axis=1)
+    context = np.sum(weights * features, axis=1, dtype=features.dtype)
+    return context, weights
+
+
+def lstm_cell(x, h_tm1, c_tm1, kernel, recurrent_kernel, bias):
+    """Keras `LSTMCell.call` (TF 2.3 default implementation=2, tanh / sigmoid):
+    z = (x.kernel + h.recurrent_kernel) + bias; split 4 -> i,f,g,o;
+    c' = sig(f)*c + sig(i)*tanh(g); h' = sig(o)*tanh(c').  Returns (h', [h', c'])."""
+    z = np.matmul(x, kernel)
+    z = z + np.matmul(h_tm1, recurrent_kernel)
+    z = z + bias
+    z0, z1, z2, z3 = np.split(z, 4, axis=1)
+    i = sigmoid(z0)
+    f = sigmoid(z1)
+    c = f * c_tm1 + i * np.tanh(z2)
+    o = sigmoid(z3)
+    h = o * np.tanh(c)
+    return h, [h, c]
+
+
+def lstm_decoder_step(p, dec_input, features, hidden, bias=None):
+    """`LstmDecoder.call` (`decoder/lstm_recurrent_decoder.py:59-116`).
+
+    The attention query and the beta gate use `hidden[-1]`, which is the LSTM CELL
+    state c (Keras state order is [h, c]; `:80`).  LSTM input is [context, embedding]
+    in that order (`:100`).  fc1 has no activation (`:106`).
+    Returns (logits[N,V], [h,c], weights[N,L,1], context[N,D] already times beta)."""
+    ids = np.asarray(dec_input).reshape(-1)
+    emb = embedding_lookup(p["embedding"], ids)
+    h_state = hidden[-1]
+    context, weights = bahdanau_attention(features, h_state, p, bias=bias)
+    beta = sigmoid(dense(h_state, p["fc3_kernel"], p["fc3_bias"]))
+    context = context * beta
+    lstm_input = np.concatenate([context, emb], axis=-1)
+    output, state = lstm_cell(lstm_input, hidden[0], hidden[1], p["lstm_kernel"],
+                              p["lstm_recurrent_kernel"], p["lstm_bias"])
+    output = dense(output, p["fc1_kernel"], p["fc1_bias"])
+    logits = dense(output, p["fc2_kernel"], p["fc2_bias"])
+    return logits, state, weights, context
+
+
+def reset_state(p, batch_size, features, reset_state_from_feat=1, bias=None):
+    """`LstmDecoder.reset_state` (`decoder/lstm_recurrent_decoder.py:118-131`):
+    state_idx = 0 + reset_state_from_feat * FeatureProjState_idx(features)."""
+    units = p["lstm_recurrent_kernel"].shape[0]
+    dt = p["lstm_kernel"].dtype
+    zeros = np.zeros((batch_size, units), dtype=dt)
+    if features is None:
+        return [zeros, zeros.copy()]
+    out = []
+    for idx in range(2):
+        proj = feature_proj_state(features, p["init%d_kernel" % idx],
+                                  p["init%d_bias" % idx], mask=bias)
+        out.append(zeros + dt.type(reset_state_from_feat) * proj)
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# beam search (beam_search/beam_search.py)
+# ----------------------------------------------------------------------------------
+
+BeamSearchState = namedtuple("BeamSearchState", ["log_probs", "finished", "lengths"])
+BeamSearchStepOutput = namedtuple("BeamSearchStepOutput",
+                                  ["scores", "predicted_ids", "beam_parent_ids"])
+BeamSearchConfig = namedtuple("BeamSearchConfig", [
+    "beam_width", "vocab_size", "eos_token", "length_penalty_weight",
+    "choose_successors_fn"])
+
+
+def create_initial_beam_state(beam_width, dtype=np.float32):
+    """`beam_search.py:70-83`."""
+    return BeamSearchState(np.zeros([beam_width], dtype),
+                           np.zeros([beam_width], bool),
+                           np.zeros([beam_width], np.int32))
+
+
+def create_initial_beam_state_batch(batch_size, beam_width, dtype=np.float32):
+    """`beam_search.py:85-98`."""
+    return BeamSearchState(np.zeros([batch_size, beam_width], dtype),
+                           np.zeros([batch_size, beam_width], bool),
+                           np.zeros([batch_size, beam_width], np.int32))
+
+
+def length_penalty(sequence_lengths, penalty_factor, dtype=np.float32):
+    """`beam_search.py:115-128`: `(5 + len)^w / 6^w`.  The numerator is an fp32
+    `tf.pow`; the denominator `(5. + 1.) ** w` is a Python double folded to the
+    tensor dtype before the division."""
+    dt = np.dtype(dtype).type
+    num = np.power(dt(5.0) + sequence_lengths.astype(dtype), dt(penalty_factor))
+    den = dt((5.0 + 1.0) ** penalty_factor)
+    return num / den
+
+
+def hyp_score(log_probs, sequence_lengths, length_penalty_weight):
+    """`beam_search.py:131-141`: log_probs / length_penalty."""
+    return log_probs / length_penalty(sequence_lengths, length_penalty_weight,
+                                      dtype=log_probs.dtype)
+
+
+def choose_top_k(scores_flat, top_k):
+    """`beam_search.py:144-148` -> `tf.nn.top_k`: values sorted descending; among
+    equal values the lower index comes first.  Works on the last axis."""
+    order = np.argsort(-scores_flat, axis=-1, kind="stable")[..., :top_k]
+    return np.take_along_axis(scores_flat, order, axis=-1), order.astype(np.int32)
+
+
+def mask_probs(probs, eos_token, finished):
+    """`beam_search.py:165-197`: rows of finished beams become
+    [f32.min ... 0@eos ... f32.min]; computed as `(1-fm)*row + fm*probs`."""
+    dt = probs.dtype.type
+    vocab_size = probs.shape[-1]
+    fm = (dt(1.0) - finished.astype(probs.dtype))[..., None]
+    non_finished = fm * probs
+    row = np.full([vocab_size], dt(F32_MIN), dtype=probs.dtype)
+    row[eos_token] = 0
+    with np.errstate(over="ignore", invalid="ignore"):
+        finished_examples = (dt(1.0) - fm) * row
+        return finished_examples + non_finished
+
+
+def batch_gather(a, b):
+    """`beam_search.py:347-358`: per-row gather `a[i, b[i, :]]`; both operands
+    round-trip through float32 and the result is float32."""
+    a32 = np.asarray(a).astype(np.float32)
+    idx = np.asarray(b).astype(np.float32).astype(np.int32)
+    return np.take_along_axis(a32, idx, axis=-1)
+
+
+def beam_search_step(time_, logits, beam_state, config):
+    """Unbatched step, `beam_search.py:200-298`.  logits[W,V]."""
+    W, V = config.beam_width, config.vocab_size
+    eos = config.eos_token
+    probs = log_softmax(logits)
+    probs = mask_probs(probs, eos, beam_state.finished)
+    with np.errstate(over="ignore", invalid="ignore"):
+        total = beam_state.log_probs[:, None] + probs
+        lengths_to_add = np.ones([W, V], np.int32)
+        lengths_to_add[:, eos] = 0                       # tf.one_hot(.., V, 0, 1)
+        add_mask = 1 - beam_state.finished.astype(np.int32)
+        new_len = beam_state.lengths[:, None] + add_mask[:, None] * lengths_to_add
+        scores = hyp_score(total, new_len, config.length_penalty_weight)
+    scores_flat = scores.reshape(-1) if int(time_) > 0 else scores[0]
+    fn = config.choose_successors_fn or choose_top_k
+    next_scores, word_indices = fn(scores_flat, W)
+    word_indices = np.asarray(word_indices).astype(np.int32)
+    next_probs = total.reshape(-1)[word_indices]
+    next_word = word_indices % V
+    next_beam = word_indices // V
+    next_finished = np.logical_or(beam_state.finished[next_beam], next_word == eos)
+    add = (next_word != eos).astype(np.int32) * (1 - next_finished.astype(np.int32))
+    next_len = beam_state.lengths[next_beam] + add
+    return (BeamSearchStepOutput(next_scores, next_word, next_beam),
+            BeamSearchState(next_probs, next_finished, next_len))
+
+
+def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None,
+                           start_offset=0):
+    """Batched step, `beam_search.py:360-543`.  logits[B,W,V]; state arrays [B,W].
+
+    At `time_ == 0` only beam `start_offset` is scored (`:454-455`); the chosen
+    indices are then in [0,V) so the parent is 0 and `next_log_probs` is gathered
+    from beam 0's totals (`:475-477`) whatever `start_offset` is."""
+    B = logits.shape[0]
+    Wl = logits.shape[1]
+    W, V = config.beam_width, config.vocab_size
+    eos = config.eos_token
+    logits_r = logits.reshape(-1, V)
+    finished_r = beam_state.finished.reshape(-1)
+    probs = (prob_fn or log_softmax)(logits_r)
+    probs = mask_probs(probs, eos, finished_r)
+    with np.errstate(over="ignore", invalid="ignore"):
+        total = beam_state.log_probs.reshape(-1, 1) + probs
+        total = total.reshape(B, -1, V)
+        lengths_to_add = np.ones([1, Wl, V], np.int32)
+        lengths_to_add[:, :, eos] = 0
+        add_mask = (1 - beam_state.finished.astype(np.int32))[..., None]
+        new_len = beam_state.lengths[..., None] + add_mask * lengths_to_add
+        scores = hyp_score(total, new_len, config.length_penalty_weight)
+    scores_flat = scores.reshape(B, -1) if int(time_) > 0 else scores[:, start_offset, :]
+    fn = config.choose_successors_fn or choose_top_k
+    next_scores, word_indices = fn(scores_flat, W)
+    word_indices = np.asarray(word_indices).astype(np.int32)
+    total_flat = total.reshape(B, -1)
+    next_probs = batch_gather(total_flat, word_indices).astype(total.dtype)
+    next_word = word_indices % V
+    next_beam = word_indices // V
+    gathered_fin = batch_gather(beam_state.finished, next_beam).astype(bool)
+    next_finished = np.logical_or(gathered_fin, next_word == eos)
+    add = (next_word != eos).astype(np.int32) * (1 - next_finished.astype(np.int32))
+    next_len = batch_gather(beam_state.lengths, next_beam).astype(np.int32) + add
+    return (BeamSearchStepOutput(next_scores, next_word, next_beam),
+            BeamSearchState(next_probs, next_finished, next_len))
+
+
+def loc_optimal_beam_path(beam_sequence):
+    """Unbatched back-tracking, `beam_search.py:300-345`.  Returns a list of T ids."""
+    if len(beam_sequence) == 0:
+        return []
+    out, state = beam_sequence[-1]
+    scores = out.scores
+    fin = state.finished.astype(scores.dtype)
+    if np.max(fin) > 0:
+        scores = scores + (scores.dtype.type(1.0) - fin) * scores.dtype.type(-1e9)
+    best = int(np.argmax(scores))
+    seq = [out.predicted_ids[best]]
+    beam = out.beam_parent_ids[best]
+    for idx in range(len(beam_sequence) - 2, -1, -1):
+        out, _ = beam_sequence[idx]
+        seq.append(out.predicted_ids[beam])
+        beam = out.beam_parent_ids[beam]
+    return list(reversed(seq))
+
+
+def loc_optimal_beam_path_batch(beam_sequence):
+    """Batched back-tracking, `beam_search.py:545-613`.  If any beam of an image is
+    finished, unfinished beams get -1e9 added (`:565-579`); argmax = first max
+    (`:582`); then parents are followed backwards (`:595-609`).  Returns a list of T
+    arrays [B,1] float32 (the dtype `batch_gather` produces), time-major."""
+    if len(beam_sequence) == 0:
+        return []
+    out, state = beam_sequence[-1]
+    scores = out.scores
+    dt = scores.dtype.type
+    fin = state.finished.astype(scores.dtype)
+    any_fin = np.max(fin, axis=-1, keepdims=True)
+    mask = (dt(1.0) - fin) * dt(-1e9)
+    scores = np.where(any_fin > 0, scores + mask, scores)
+    best = np.argmax(scores, axis=-1)[:, None]
+    seq = [batch_gather(out.predicted_ids, best)]
+    beam = batch_gather(out.beam_parent_ids, best)
+    for idx in range(len(beam_sequence) - 2, -1, -1):
+        out, _ = beam_sequence[idx]
+        seq.append(batch_gather(out.predicted_ids, beam))
+        beam = batch_gather(out.beam_parent_ids, beam)
+    return list(reversed(seq))
+
+
+# ----------------------------------------------------------------------------------
+# whole-sequence driver
+# ----------------------------------------------------------------------------------
+
+def tile_features(features, beam_width, tile_mode):
+    """`tf.tile(features, [W,1,1])` (`recurrent_example.py:486`) puts image r % B in
+    row r ("reference"), although logits are later read as row = image*W + beam
+    (`:541`).  "repeat" is the self-consistent layout (row r -> image r // W)."""
+    if tile_mode == "reference":
+        return np.tile(features, (beam_width, 1, 1))
+    if tile_mode == "repeat":
+        return np.repeat(features, beam_width, axis=0)
+    raise ValueError("tile_mode must be 'reference' or 'repeat'")
+
+
+def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id,
+                                   length_penalty_weight=1.0, tile_mode="reference",
+                                   reset_state_from_feat=1, return_trace=False):
+    """`predict_image_caption_sequence` (`recurrent_example.py:477-562`).
+
+    encoder -> tile -> reset_state -> T x (decoder step, beam step) -> back-track.
+    The recurrent state is NOT reordered by parent beam between steps (`:526-529`,
+    `:558`): only the token ids come from the beam search.  No early exit (`:517`).
+    Returns int32 tokens [B,T] (and the per-step trace if asked)."""
+    B = img.shape[0]
+    W = beam_width
+    features = mlp_encoder(img, p["enc_kernel"], p["enc_bias"])
+    features = tile_features(features, W, tile_mode)
+    dec_input = np.full([B * W, 1], start_id, np.int32)
+    hidden = reset_state(p, B * W, features, reset_state_from_feat)
+    V = p["fc2_kernel"].shape[1]
+    state = create_initial_beam_state_batch(B, W, dtype=img.dtype)
+    config = BeamSearchConfig(W, V, eos_id, length_penalty_weight, choose_top_k)
+    seq = []
+    trace = []
+    for i in range(max_len):
+        logits, hidden, weights, ctx = lstm_decoder_step(p, dec_input, features, hidden)
+        logits3 = logits.reshape(-1, W, V)
+        out, state = beam_search_step_batch(i, logits3, state, config)
+        seq.append((out, state))
+        if return_trace:
+            trace.append({"logits": logits3, "out": out, "state": state,
+                          "h": hidden[0], "c": hidden[1], "ctx": ctx,
+                          "weights": weights})
+        dec_input = out.predicted_ids.reshape(-1, 1)
+    path = loc_optimal_beam_path_batch(seq)
+    tokens = np.concatenate(path, axis=1).astype(np.int32)    # [B,T]
+    if return_trace:
+        return tokens, trace
+    return tokens
+
+
+# ----------------------------------------------------------------------------------
+# synthetic weights / inputs (Keras default initialisers)
+# ----------------------------------------------------------------------------------
+
+def _glorot(rng, fan_in, fan_out, shape=None):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape or (fan_in, fan_out)).astype(np.float32)
+
+
+def make_params(seed, F, D, E, H, V, U=None, C=None):
+    """Synthetic weights: Glorot-uniform Dense/LSTM kernels (Keras default; the
+    decoder passes `recurrent_initializer='glorot_uniform'`,
+    `lstm_recurrent_decoder.py:23,36`), zero biases except the LSTM forget-gate slice
+    (unit_forget_bias), embedding U(-0.05, 0.05)."""
+    U = U or H
+    C = C or D
+    rng = np.random.default_rng(seed)
+    p = {}
+    p["enc_kernel"] = _glorot(rng, F, D)
+    p["enc_bias"] = np.zeros(D, np.float32)
+    p["embedding"] = rng.uniform(-0.05, 0.05, size=(V, E)).astype(np.float32)
+    for idx in range(2):
+        p["init%d_kernel" % idx] = _glorot(rng, D, H)
+        p["init%d_bias" % idx] = np.zeros(H, np.float32)
+    p["att_W1_kernel"] = _glorot(rng, D, U)
+    p["att_W1_bias"] = np.zeros(U, np.float32)
+    p["att_W2_kernel"] = _glorot(rng, H, U)
+    p["att_W2_bias"] = np.zeros(U, np.float32)
+    p["att_V_kernel"] = _glorot(rng, U, 1)
+    p["att_V_bias"] = np.zeros(1, np.float32)
+    p["fc3_kernel"] = _glorot(rng, H, 1)
+    p["fc3_bias"] = np.zeros(1, np.float32)
+    p["lstm_kernel"] = _glorot(rng, C + E, 4 * H)
+    p["lstm_recurrent_kernel"] = _glorot(rng, H, 4 * H)
+    b = np.zeros(4 * H, np.float32)
+    b[H:2 * H] = 1.0
+    p["lstm_bias"] = b
+    p["fc1_kernel"] = _glorot(rng, H, H)
+    p["fc1_bias"] = np.zeros(H, np.float32)
+    p["fc2_kernel"] = _glorot(rng, H, V)
+    p["fc2_bias"] = np.zeros(V, np.float32)
+    return p
+
+
+def perturb_biases(p, seed, scale=0.05):
+    """Give every bias a non-zero value so tests exercise the bias adds."""
+    rng = np.random.default_rng(seed)
+    q = dict(p)
+    for k, v in p.items():
+        if k.endswith("_bias"):
+            q[k] = (v + rng.normal(0, scale, size=v.shape)).astype(np.float32)
+    return q
+
+
+def make_images(seed, B, L, F):
+    """Synthetic CNN features: max(0, N(0,1)) * 0.5 (non-negative, half zeros)."""
+    rng = np.random.default_rng(seed)
+    return (np.maximum(rng.standard_normal((B, L, F)), 0.0) * 0.5).astype(np.float32)
+
+
+def cast_params(p, dtype):
+    return {k: v.astype(dtype) for k, v in p.items()}
