@@ -1,0 +1,111 @@
+"""ctypes binding of libicap.so (the C ABI declared in include/icap.h).
+
+The HIP library is the only compute path of this package: if it is missing the
+import fails loudly instead of falling back to anything else."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicap.so")
+
+ICAP_OK = 0
+ACT_NONE, ACT_RELU = 0, 1
+TILE_REFERENCE, TILE_REPEAT = 0, 1
+PRECISION_FP32, PRECISION_BF16 = 0, 1
+MAX_BEAM_WIDTH = 16
+K_NAMES = ("encode", "feat_proj", "init_state", "attn_query", "attention", "lstm", "fc1",
+           "vocab", "beam", "backtrack")
+
+
+class IcapError(RuntimeError):
+    """A libicap entry point returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__("icap error %d: %s" % (code, message))
+        self.code = code
+
+
+class IcapConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "W", "L", "F", "D", "E", "H", "U", "V", "T",
+                                         "start_id", "eos_id", "tile_mode", "precision")] + [
+        ("length_penalty_weight", C.c_double),
+        ("reset_state_from_feat", C.c_float),
+        ("reserved", C.c_int32)]
+
+
+WEIGHT_FIELDS = ("enc_kernel", "enc_bias", "embedding", "init_h_kernel", "init_h_bias",
+                 "init_c_kernel", "init_c_bias", "att_w1_kernel", "att_w1_bias",
+                 "att_w2_kernel", "att_w2_bias", "att_v_kernel", "att_v_bias", "fc3_kernel",
+                 "fc3_bias", "lstm_kernel", "lstm_recurrent_kernel", "lstm_bias", "fc1_kernel",
+                 "fc1_bias", "fc2_kernel", "fc2_bias")
+
+
+class IcapWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in WEIGHT_FIELDS]
+
+
+_P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
+
+# name -> argtypes; every entry point of include/icap.h
+SIGNATURES = {
+    "icap_version": ([], C.c_int),
+    "icap_last_error": ([C.c_char_p, C.c_size_t], C.c_size_t),
+    "icap_dense_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "icap_pool_features_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_expand_rows_f32": ([_P, _P, _I, _I, _I, _F, _I, _P], C.c_int),
+    "icap_embedding_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_attention_f32": ([_P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P,
+                            _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_lstm_step_f32": ([_P] * 11 + [_I] * 5 + [_P], C.c_int),
+    "icap_beam_step_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
+                            _I, _I, _I, _P], C.c_int),
+    "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
+    "icap_engine_create": ([C.POINTER(IcapConfig), C.POINTER(IcapWeights), C.POINTER(_P)], C.c_int),
+    "icap_engine_destroy": ([_P], C.c_int),
+    "icap_engine_workspace_bytes": ([_P], C.c_size_t),
+    "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
+    "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
+    "icap_engine_set_timing": ([_P, _I], C.c_int),
+    "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libicap.so once and declares every signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own HIP runtime (same soname as /opt/rocm's); importing it first
+    # makes libicap.so bind to that one, so torch's device pointers and streams are valid
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "image_caption_amd: %s is missing - the HIP extension is the only compute path; "
+            "build it with `make -C image_caption_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def last_error():
+    lib = load()
+    buf = C.create_string_buffer(1024)
+    lib.icap_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != ICAP_OK:
+        raise IcapError(rc, last_error())
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

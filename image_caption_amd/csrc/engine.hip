@@ -1,0 +1,401 @@
+// C ABI of libicap: argument checking wrappers around the kernels plus the fused
+// whole-sequence decode engine (workspace, step loop, optional per-kernel timing).
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "icap_common.h"
+
+namespace icap {
+
+std::string& last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+// kernels (gemm_f32.hip, attention.hip, beam.hip)
+int dense_f32(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int lstm_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
+                  const float*, const float*, const float*, const float*, float*, float*, int, int,
+                  int, int, int, hipStream_t);
+int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
+                  const float*, const float*, float, float*, float*, int, int, int, int, int, int,
+                  int, int, hipStream_t);
+int pool_features_f32(const float*, const float*, float*, int, int, int, hipStream_t);
+int expand_rows_f32(const float*, float*, int, int, int, float, int, hipStream_t);
+int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
+int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
+                  double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
+                  int, hipStream_t);
+int backtrack(const int32_t*, const int32_t*, const float*, const uint8_t*, int32_t*, int32_t*,
+              float*, int, int, int, hipStream_t);
+
+namespace {
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+}  // namespace
+
+}  // namespace icap
+
+struct icap_engine {
+  icap_config cfg;
+  icap_weights w;
+  int device = 0;
+  float att_v_bias = 0.f, fc3_bias = 0.f;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  // workspace views
+  float *features, *pf, *pooled, *init_h, *init_c;
+  float *h[2], *c, *q, *ctx, *fc1o, *logits;
+  float *lp, *hist_scores, *hist_lp;
+  int32_t *len, *hist_ids, *hist_parents, *start_ids;
+  uint8_t* fin;
+  // timing
+  bool timing = false;
+  struct Span { int cls; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  size_t spans_used = 0;
+};
+
+namespace icap {
+namespace {
+
+struct Carver {
+  size_t off = 0;
+  template <typename T>
+  size_t take(size_t n) {
+    off = (off + 255) / 256 * 256;
+    const size_t o = off;
+    off += n * sizeof(T);
+    return o;
+  }
+};
+
+int check_config(const icap_config& c) {
+  ICAP_REQUIRE(c.B > 0 && c.W > 0 && c.L > 0 && c.F > 0 && c.D > 0 && c.E > 0 && c.H > 0 &&
+                   c.U > 0 && c.V > 0 && c.T > 0,
+               "engine: every dimension must be positive");
+  ICAP_REQUIRE(c.W <= ICAP_MAX_BEAM_WIDTH, "engine: beam width %d exceeds %d", c.W,
+               ICAP_MAX_BEAM_WIDTH);
+  ICAP_REQUIRE(c.W <= c.V, "engine: beam width exceeds vocab size");
+  ICAP_REQUIRE(c.start_id >= 0 && c.start_id < c.V, "engine: start_id outside the vocabulary");
+  ICAP_REQUIRE(c.tile_mode == ICAP_TILE_REFERENCE || c.tile_mode == ICAP_TILE_REPEAT,
+               "engine: unknown tile_mode %d", c.tile_mode);
+  ICAP_REQUIRE(c.U % 4 == 0 && c.D % 4 == 0, "engine: U and D must be multiples of 4");
+  if (c.precision != ICAP_PRECISION_FP32)
+    return fail(ICAP_ERR_UNSUPPORTED, "engine: precision %d is not built", c.precision);
+  ICAP_REQUIRE((long long)c.B * c.W * (long long)c.V < (1LL << 40), "engine: logits too large");
+  return ICAP_OK;
+}
+
+struct Timed {
+  icap_engine* e;
+  hipStream_t s;
+  bool on;
+  size_t idx = 0;
+  Timed(icap_engine* e_, int cls, hipStream_t s_) : e(e_), s(s_), on(e_->timing) {
+    if (!on) return;
+    if (e->spans_used == e->spans.size()) {
+      icap_engine::Span sp;
+      sp.cls = cls;
+      if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
+        on = false;
+        return;
+      }
+      e->spans.push_back(sp);
+    }
+    idx = e->spans_used++;
+    e->spans[idx].cls = cls;
+    hipEventRecord(e->spans[idx].a, s);
+  }
+  ~Timed() {
+    if (on) hipEventRecord(e->spans[idx].b, s);
+  }
+};
+
+#define ICAP_TRY(expr)            \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != ICAP_OK) return rc_; \
+  } while (0)
+
+int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_score,
+                hipStream_t s) {
+  const icap_config& c = e->cfg;
+  const icap_weights& w = e->w;
+  const int N = c.B * c.W;
+  const int BL = c.B * c.L;
+
+  {  // K0: features = relu(img . Wenc + benc)
+    Timed t(e, ICAP_K_ENCODE, s);
+    ICAP_TRY(dense_f32(img, w.enc_kernel, w.enc_bias, e->features, BL, c.F, c.D, ICAP_ACT_RELU, s));
+  }
+  {  // K1: PF = features . W1 + b1   (step invariant, per image)
+    Timed t(e, ICAP_K_FEAT_PROJ, s);
+    ICAP_TRY(dense_f32(e->features, w.att_w1_kernel, w.att_w1_bias, e->pf, BL, c.D, c.U,
+                       ICAP_ACT_NONE, s));
+  }
+  {  // K2: h0, c0 per image, expanded to the beam rows
+    Timed t(e, ICAP_K_INIT_STATE, s);
+    ICAP_TRY(pool_features_f32(e->features, nullptr, e->pooled, c.B, c.L, c.D, s));
+    ICAP_TRY(dense_f32(e->pooled, w.init_h_kernel, w.init_h_bias, e->init_h, c.B, c.D, c.H,
+                       ICAP_ACT_NONE, s));
+    ICAP_TRY(dense_f32(e->pooled, w.init_c_kernel, w.init_c_bias, e->init_c, c.B, c.D, c.H,
+                       ICAP_ACT_NONE, s));
+    ICAP_TRY(expand_rows_f32(e->init_h, e->h[0], c.B, c.W, c.H, c.reset_state_from_feat,
+                             c.tile_mode, s));
+    ICAP_TRY(expand_rows_f32(e->init_c, e->c, c.B, c.W, c.H, c.reset_state_from_feat, c.tile_mode,
+                             s));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, e->start_ids,
+                       c.start_id, N);
+    ICAP_LAUNCH_CHECK("fill_i32_kernel");
+    // initial beam state: zeros (beam_search.py:85-98)
+    ICAP_HIP(hipMemsetAsync(e->lp, 0, sizeof(float) * N, s));
+    ICAP_HIP(hipMemsetAsync(e->len, 0, sizeof(int32_t) * N, s));
+    ICAP_HIP(hipMemsetAsync(e->fin, 0, N, s));
+  }
+
+  const int stride_g = c.tile_mode == ICAP_TILE_REPEAT ? c.W : 1;
+  const int stride_k = c.tile_mode == ICAP_TILE_REPEAT ? 1 : c.B;
+  int cur = 0;
+  for (int t = 0; t < c.T; ++t) {
+    const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
+    {  // K4: q = W2(c) + b2      (the query is the LSTM cell state)
+      Timed tm(e, ICAP_K_ATTN_QUERY, s);
+      ICAP_TRY(dense_f32(e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N, c.H, c.U, ICAP_ACT_NONE, s));
+    }
+    {  // K5: additive attention + beta gate
+      Timed tm(e, ICAP_K_ATTENTION, s);
+      ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
+                             e->c, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
+                             stride_k, c.L, c.U, c.D, c.H, s));
+    }
+    {  // K6: LSTM cell on [ctx | emb(ids) | h]
+      Timed tm(e, ICAP_K_LSTM, s);
+      ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->h[cur], e->c, w.lstm_kernel,
+                             w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1], e->c, N, c.D,
+                             c.E, c.H, c.V, s));
+    }
+    cur ^= 1;
+    {  // K7: fc1
+      Timed tm(e, ICAP_K_FC1, s);
+      ICAP_TRY(dense_f32(e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N, c.H, c.H, ICAP_ACT_NONE, s));
+    }
+    {  // K8: vocab projection
+      Timed tm(e, ICAP_K_VOCAB, s);
+      ICAP_TRY(dense_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N, c.H, c.V, ICAP_ACT_NONE, s));
+    }
+    {  // K9: beam step; outputs recorded per step, state updated in place
+      Timed tm(e, ICAP_K_BEAM, s);
+      ICAP_TRY(beam_step_f32(e->logits, e->lp, e->fin, e->len, t, 0, c.eos_id,
+                             c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
+                             e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N, e->lp,
+                             e->fin, e->len, c.B, c.W, c.V, s));
+      ICAP_HIP(hipMemcpyAsync(e->hist_lp + (size_t)t * N, e->lp, sizeof(float) * N,
+                              hipMemcpyDeviceToDevice, s));
+    }
+  }
+  {  // K10
+    Timed tm(e, ICAP_K_BACKTRACK, s);
+    ICAP_TRY(backtrack(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N, e->fin,
+                       tokens, nullptr, best_score, c.T, c.B, c.W, s));
+  }
+  return ICAP_OK;
+}
+
+}  // namespace
+}  // namespace icap
+
+using namespace icap;
+
+extern "C" {
+
+int icap_version(void) { return 100; }
+
+size_t icap_last_error(char* buf, size_t len) {
+  const std::string& m = last_error();
+  if (buf && len) {
+    const size_t n = m.size() < len - 1 ? m.size() : len - 1;
+    memcpy(buf, m.data(), n);
+    buf[n] = 0;
+  }
+  return m.size();
+}
+
+int icap_dense_f32(const float* x, const float* w, const float* bias, float* y, int M, int K,
+                   int N, int act, icap_stream_t stream) {
+  return dense_f32(x, w, bias, y, M, K, N, act, (hipStream_t)stream);
+}
+
+int icap_pool_features_f32(const float* features, const float* mask, float* pooled, int G, int L,
+                           int D, icap_stream_t stream) {
+  return pool_features_f32(features, mask, pooled, G, L, D, (hipStream_t)stream);
+}
+
+int icap_expand_rows_f32(const float* src, float* dst, int B, int W, int H, float scale,
+                         int tile_mode, icap_stream_t stream) {
+  return expand_rows_f32(src, dst, B, W, H, scale, tile_mode, (hipStream_t)stream);
+}
+
+int icap_embedding_f32(const float* table, const int32_t* ids, float* out, int N, int V, int E,
+                       icap_stream_t stream) {
+  return embedding_f32(table, ids, out, N, V, E, (hipStream_t)stream);
+}
+
+int icap_attention_f32(const float* pf, const float* features, const float* q, const float* v,
+                       float bv, const float* score_bias, const float* gate_state,
+                       const float* gate_w, float gate_b, float* ctx, float* weights, int G,
+                       int rows_per_group, int row_stride_g, int row_stride_k, int L, int U, int D,
+                       int H, icap_stream_t stream) {
+  return attention_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
+                       G, rows_per_group, row_stride_g, row_stride_k, L, U, D, H,
+                       (hipStream_t)stream);
+}
+
+int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
+                       const float* h, const float* c, const float* kernel,
+                       const float* recurrent_kernel, const float* bias, float* h_out,
+                       float* c_out, int N, int C, int E, int H, int V, icap_stream_t stream) {
+  return lstm_step_f32(ctx, emb, table, ids, h, c, kernel, recurrent_kernel, bias, h_out, c_out, N,
+                       C, E, H, V, (hipStream_t)stream);
+}
+
+int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                       const int32_t* lengths, int time, int start_offset, int eos_token,
+                       double length_penalty_weight, int input_is_log_prob, float* scores,
+                       int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                       uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
+                       icap_stream_t stream) {
+  return beam_step_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
+                       length_penalty_weight, input_is_log_prob, scores, predicted_ids, parent_ids,
+                       next_log_probs, next_finished, next_lengths, B, W, V, (hipStream_t)stream);
+}
+
+int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
+                   const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,
+                   float* best_score, int T, int B, int W, icap_stream_t stream) {
+  return backtrack(ids, parents, last_scores, last_finished, tokens, best_beam, best_score, T, B, W,
+                   (hipStream_t)stream);
+}
+
+int icap_engine_create(const icap_config* config, const icap_weights* weights, icap_engine** out) {
+  ICAP_REQUIRE(config && weights && out, "icap_engine_create: null argument");
+  *out = nullptr;
+  ICAP_TRY(check_config(*config));
+  const void* const* wp = reinterpret_cast<const void* const*>(weights);
+  for (size_t i = 0; i < sizeof(icap_weights) / sizeof(void*); ++i)
+    ICAP_REQUIRE(wp[i] != nullptr, "icap_engine_create: weight pointer %zu is null", i);
+  icap_engine* e = new (std::nothrow) icap_engine();
+  ICAP_REQUIRE(e, "icap_engine_create: out of host memory");
+  e->cfg = *config;
+  e->w = *weights;
+  const icap_config& c = e->cfg;
+  const size_t N = (size_t)c.B * c.W, BL = (size_t)c.B * c.L, TN = (size_t)c.T * N;
+  Carver cv;
+  const size_t o_features = cv.take<float>(BL * c.D), o_pf = cv.take<float>(BL * c.U),
+               o_pooled = cv.take<float>((size_t)c.B * c.D),
+               o_init_h = cv.take<float>((size_t)c.B * c.H),
+               o_init_c = cv.take<float>((size_t)c.B * c.H), o_h0 = cv.take<float>(N * c.H),
+               o_h1 = cv.take<float>(N * c.H), o_c = cv.take<float>(N * c.H),
+               o_q = cv.take<float>(N * c.U), o_ctx = cv.take<float>(N * c.D),
+               o_fc1 = cv.take<float>(N * c.H), o_logits = cv.take<float>(N * c.V),
+               o_lp = cv.take<float>(N), o_hs = cv.take<float>(TN), o_hl = cv.take<float>(TN),
+               o_len = cv.take<int32_t>(N), o_hi = cv.take<int32_t>(TN),
+               o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N);
+  e->ws_bytes = (cv.off + 255) / 256 * 256;
+  hipError_t err = hipGetDevice(&e->device);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
+  if (err == hipSuccess)
+    err = hipMemcpy(&e->att_v_bias, weights->att_v_bias, sizeof(float), hipMemcpyDeviceToHost);
+  if (err == hipSuccess)
+    err = hipMemcpy(&e->fc3_bias, weights->fc3_bias, sizeof(float), hipMemcpyDeviceToHost);
+  if (err != hipSuccess) {
+    if (e->ws) hipFree(e->ws);
+    delete e;
+    return fail(ICAP_ERR_HIP, "icap_engine_create: %s", hipGetErrorString(err));
+  }
+  char* b = e->ws;
+  e->features = (float*)(b + o_features); e->pf = (float*)(b + o_pf);
+  e->pooled = (float*)(b + o_pooled); e->init_h = (float*)(b + o_init_h);
+  e->init_c = (float*)(b + o_init_c); e->h[0] = (float*)(b + o_h0); e->h[1] = (float*)(b + o_h1);
+  e->c = (float*)(b + o_c); e->q = (float*)(b + o_q); e->ctx = (float*)(b + o_ctx);
+  e->fc1o = (float*)(b + o_fc1); e->logits = (float*)(b + o_logits); e->lp = (float*)(b + o_lp);
+  e->hist_scores = (float*)(b + o_hs); e->hist_lp = (float*)(b + o_hl);
+  e->len = (int32_t*)(b + o_len); e->hist_ids = (int32_t*)(b + o_hi);
+  e->hist_parents = (int32_t*)(b + o_hp); e->start_ids = (int32_t*)(b + o_si);
+  e->fin = (uint8_t*)(b + o_fin);
+  *out = e;
+  return ICAP_OK;
+}
+
+int icap_engine_destroy(icap_engine* e) {
+  if (!e) return ICAP_OK;
+  for (auto& sp : e->spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  if (e->ws) hipFree(e->ws);
+  delete e;
+  return ICAP_OK;
+}
+
+size_t icap_engine_workspace_bytes(const icap_engine* e) { return e ? e->ws_bytes : 0; }
+
+int icap_decode(icap_engine* e, const float* img, int32_t* tokens, float* best_score,
+                icap_stream_t stream) {
+  ICAP_REQUIRE(e && img && tokens, "icap_decode: null argument");
+  if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;  // bound the event pool
+  return decode_impl(e, img, tokens, best_score, (hipStream_t)stream);
+}
+
+int icap_engine_trace(const icap_engine* e, int32_t* ids, int32_t* parents, float* scores,
+                      float* log_probs, icap_stream_t stream) {
+  ICAP_REQUIRE(e, "icap_engine_trace: null engine");
+  const size_t n = (size_t)e->cfg.T * e->cfg.B * e->cfg.W * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (ids) ICAP_HIP(hipMemcpyAsync(ids, e->hist_ids, n, hipMemcpyDeviceToDevice, s));
+  if (parents) ICAP_HIP(hipMemcpyAsync(parents, e->hist_parents, n, hipMemcpyDeviceToDevice, s));
+  if (scores) ICAP_HIP(hipMemcpyAsync(scores, e->hist_scores, n, hipMemcpyDeviceToDevice, s));
+  if (log_probs) ICAP_HIP(hipMemcpyAsync(log_probs, e->hist_lp, n, hipMemcpyDeviceToDevice, s));
+  return ICAP_OK;
+}
+
+int icap_engine_set_timing(icap_engine* e, int enabled) {
+  ICAP_REQUIRE(e, "icap_engine_set_timing: null engine");
+  e->timing = enabled != 0;
+  e->spans_used = 0;
+  return ICAP_OK;
+}
+
+int icap_engine_kernel_times(icap_engine* e, float* ms, int32_t* launches) {
+  ICAP_REQUIRE(e && ms && launches, "icap_engine_kernel_times: null argument");
+  for (int i = 0; i < ICAP_K_COUNT; ++i) {
+    ms[i] = 0.f;
+    launches[i] = 0;
+  }
+  for (size_t i = 0; i < e->spans_used; ++i) {
+    auto& sp = e->spans[i];
+    ICAP_HIP(hipEventSynchronize(sp.b));
+    float t = 0.f;
+    ICAP_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+    ms[sp.cls] += t;
+    launches[sp.cls] += 1;
+  }
+  return ICAP_OK;
+}
+
+}  // extern "C"

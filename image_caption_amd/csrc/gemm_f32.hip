@@ -1,0 +1,425 @@
+// Exact-f32 MFMA GEMM kernels (v_mfma_f32_32x32x2_f32) for gfx950:
+//   dense_f32 : y = act(x . w + bias)            (all Dense layers on the path)
+//   lstm_f32  : Keras LSTMCell step with the [ctx | emb | h] concatenation, the
+//               embedding gather and the i,f,g,o epilogue fused into the GEMM.
+//
+// Tiling.  A workgroup owns a BM x BN output tile and walks K in steps of BK = 32.
+// Global -> registers -> LDS staging is double buffered (one barrier per K step);
+// the loads of step t+1 are in flight while step t is multiplied.
+//   A tile in LDS : float4 As[BK/4][BM+1]   As[kq][m] = A[m][4kq .. 4kq+3]
+//   B tile in LDS : float  Bs[BK][BN]
+// The MFMA takes one A and one B value per lane: lane l holds A[i = l&31][k = l>>5]
+// and B[k = l>>5][j = l&31].  Inside a group of 8 k values, lane half h = l>>5 takes
+// k = 4h + s at sub-step s, so one ds_read_b128 of As feeds four MFMAs.  The order in
+// which k is summed inside a group is therefore permuted, which is irrelevant for
+// the sum being complete.  Result layout of a 32x32 tile: column = l&31,
+// row = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r.
+#include "icap_common.h"
+
+namespace icap {
+namespace {
+
+constexpr int BK = 32;
+
+struct DenseArgs {
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int act;
+  int tiles_m, tiles_n;
+};
+
+// 16-byte load when the whole vector is in range, element-wise guarded otherwise.
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ row_ptr, bool row_ok,
+                                        int col, int ncols) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok) return v;
+  if (VEC && col + 3 < ncols) {
+    v = *reinterpret_cast<const float4*>(row_ptr + col);
+  } else {
+    if (col + 0 < ncols) v.x = row_ptr[col + 0];
+    if (col + 1 < ncols) v.y = row_ptr[col + 1];
+    if (col + 2 < ncols) v.z = row_ptr[col + 2];
+    if (col + 3 < ncols) v.w = row_ptr[col + 3];
+  }
+  return v;
+}
+
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so each XCD
+// walks whole columns of tiles (same B panel, all M tiles) before the next column.
+__device__ __forceinline__ bool tile_of_block(int pid, int tiles_m, int tiles_n, int& tm,
+                                              int& tn) {
+  const int xcd = pid & 7;
+  const int local = pid >> 3;
+  tm = local % tiles_m;
+  tn = xcd + 8 * (local / tiles_m);
+  return tn < tiles_n;
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_LD = (BM * BK / 4) / NT;  // float4 loads per thread per K step
+  constexpr int B_LD = (BK * BN / 4) / NT;
+  static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the block");
+
+  __shared__ float4 As[2][BK / 4][BM + 1];
+  __shared__ float Bs[2][BK][BN];
+
+  int tile_m, tile_n;
+  if (!tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n)) return;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_LD], rb[B_LD];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int f = tid + i * NT;
+      const int kq = f % (BK / 4);
+      const int row = f / (BK / 4);
+      const int gm = m0 + row;
+      ra[i] = load4<VEC>(p.A + (size_t)gm * p.lda, gm < p.M, k0 + 4 * kq, p.K);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int f = tid + i * NT;
+      const int cg = f % (BN / 4);
+      const int k = f / (BN / 4);
+      const int gk = k0 + k;
+      rb[i] = load4<VEC>(p.B + (size_t)gk * p.ldb, gk < p.K, n0 + 4 * cg, p.N);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int f = tid + i * NT;
+      As[buf][f % (BK / 4)][f / (BK / 4)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int f = tid + i * NT;
+      *reinterpret_cast<float4*>(&Bs[buf][f / (BN / 4)][4 * (f % (BN / 4))]) = rb[i];
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) load_tiles((t + 1) * BK);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 a[TM];
+      float b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * g + half][(wm * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          b[j][s] = Bs[buf][8 * g + 4 * half + s][(wn * TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j][3], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (t + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: bias, activation, store (two 128-byte row segments per instruction)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+          p.C[(size_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// LSTM step.  Workgroup = 4 waves stacked along M (32 rows each); every wave owns the
+// four gate tiles (i,f,g,o) of the same 32 hidden units, so the cell update needs no
+// exchange between lanes: register r of the four accumulators is the same (row, unit).
+// ---------------------------------------------------------------------------------
+struct LstmArgs {
+  const float* ctx;    // [N,C]
+  const float* emb;    // [N,E] or null
+  const float* table;  // [V,E] or null
+  const int32_t* ids;  // [N] or null
+  const float* h;      // [N,H]
+  const float* c;      // [N,H]
+  const float* kernel;     // [C+E,4H]
+  const float* recurrent;  // [H,4H]
+  const float* bias;       // [4H]
+  float* h_out;
+  float* c_out;
+  int N, C, E, H, V;
+  int tiles_m, tiles_j;
+};
+
+constexpr int LSTM_BM = 128;
+constexpr int LSTM_BJ = 32;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
+  constexpr int NT = 256;
+  constexpr int BM = LSTM_BM, BN = 4 * LSTM_BJ;
+  constexpr int A_LD = (BM * BK / 4) / NT;  // 4
+  constexpr int B_LD = (BK * BN / 4) / NT;  // 4
+
+  __shared__ float4 As[2][BK / 4][BM + 1];
+  __shared__ float Bs[2][BK][BN];
+  __shared__ int row_src[BM];  // embedding row of each tile row (-1: zero row)
+
+  const int tile_m = blockIdx.x % p.tiles_m;
+  const int tile_j = blockIdx.x / p.tiles_m;
+  const int m0 = tile_m * BM;
+  const int j0 = tile_j * LSTM_BJ;
+  const int K = p.C + p.E + p.H;
+  const int CE = p.C + p.E;
+  const int H4 = 4 * p.H;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  if (tid < BM) {
+    const int gm = m0 + tid;
+    int src = -1;
+    if (gm < p.N) {
+      if (p.ids) {
+        const int id = p.ids[gm];
+        src = (id >= 0 && id < p.V) ? id : -1;
+      } else {
+        src = gm;
+      }
+    }
+    row_src[tid] = src;
+  }
+  __syncthreads();
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  float4 ra[A_LD], rb[B_LD];
+  const float* emb_base = p.ids ? p.table : p.emb;
+
+  // A[m][k]: k < C from ctx, k < C+E from the embedding row, else from h.  A float4
+  // never straddles two sources on the VEC path because C and E are multiples of 4.
+  auto load_a4 = [&](int row, int k) -> float4 {
+    const int gm = m0 + row;
+    if (gm >= p.N || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+      if (k < p.C) return *reinterpret_cast<const float4*>(p.ctx + (size_t)gm * p.C + k);
+      if (k < CE) {
+        const int src = row_src[row];
+        if (src < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(emb_base + (size_t)src * p.E + (k - p.C));
+      }
+      return *reinterpret_cast<const float4*>(p.h + (size_t)gm * p.H + (k - CE));
+    }
+    float e[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = k + s;
+      float v = 0.f;
+      if (kk < p.C) {
+        v = p.ctx[(size_t)gm * p.C + kk];
+      } else if (kk < CE) {
+        const int src = row_src[row];
+        v = src < 0 ? 0.f : emb_base[(size_t)src * p.E + (kk - p.C)];
+      } else if (kk < K) {
+        v = p.h[(size_t)gm * p.H + (kk - CE)];
+      }
+      e[s] = v;
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
+  };
+  // B[k][c]: tile column c = gate*32 + jj maps to weight column gate*H + j0 + jj.
+  auto load_b4 = [&](int k, int c) -> float4 {
+    if (k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gate = c / LSTM_BJ;
+    const int jj = c % LSTM_BJ;
+    const float* rowp = (k < CE) ? p.kernel + (size_t)k * H4 : p.recurrent + (size_t)(k - CE) * H4;
+    rowp += gate * p.H;
+    return load4<VEC>(rowp, true, j0 + jj, p.H);
+  };
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int f = tid + i * NT;
+      ra[i] = load_a4(f / (BK / 4), k0 + 4 * (f % (BK / 4)));
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int f = tid + i * NT;
+      rb[i] = load_b4(k0 + f / (BN / 4), 4 * (f % (BN / 4)));
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int f = tid + i * NT;
+      As[buf][f % (BK / 4)][f / (BK / 4)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int f = tid + i * NT;
+      *reinterpret_cast<float4*>(&Bs[buf][f / (BN / 4)][4 * (f % (BN / 4))]) = rb[i];
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) load_tiles((t + 1) * BK);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      const float4 a = As[buf][2 * g + half][wave * 32 + l31];
+      float b[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[j][s] = Bs[buf][8 * g + 4 * half + s][j * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j][0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j][2], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j][3], acc[j], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int j = j0 + l31;
+  if (j >= p.H) return;
+  const float bi = p.bias[j], bf = p.bias[p.H + j], bg = p.bias[2 * p.H + j],
+              bo = p.bias[3 * p.H + j];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row < p.N) {
+      const float ig = fast_sigmoid(acc[0][r] + bi);
+      const float fg = fast_sigmoid(acc[1][r] + bf);
+      const float gg = fast_tanh(acc[2][r] + bg);
+      const float og = fast_sigmoid(acc[3][r] + bo);
+      const float c_new = fg * p.c[(size_t)row * p.H + j] + ig * gg;
+      p.c_out[(size_t)row * p.H + j] = c_new;
+      p.h_out[(size_t)row * p.H + j] = og * fast_tanh(c_new);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
+  DenseArgs p = a;
+  p.tiles_m = ceil_div(p.M, BM);
+  p.tiles_n = ceil_div(p.N, BN);
+  const int grid = 8 * ceil_div(p.tiles_n, 8) * p.tiles_m;
+  if (vec)
+    hipLaunchKernelGGL((dense_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(WM * WN * 64),
+                       0, s, p);
+  else
+    hipLaunchKernelGGL((dense_f32_kernel<BM, BN, WM, WN, false>), dim3(grid),
+                       dim3(WM * WN * 64), 0, s, p);
+  ICAP_LAUNCH_CHECK("dense_f32_kernel");
+  return ICAP_OK;
+}
+
+}  // namespace
+
+int dense_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+              int act, hipStream_t s) {
+  ICAP_REQUIRE(x && w && y, "dense_f32: null pointer");
+  ICAP_REQUIRE(M > 0 && K > 0 && N > 0, "dense_f32: M, K, N must be positive (got %d, %d, %d)", M,
+               K, N);
+  ICAP_REQUIRE(act == ICAP_ACT_NONE || act == ICAP_ACT_RELU, "dense_f32: unknown activation %d",
+               act);
+  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0};
+  const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w);
+  // 128x128 tiles when they fill the chip, 64x64 tiles for the small projections.
+  const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+  if (big_tiles >= 192) return launch_dense<128, 128, 2, 2>(a, vec, s);
+  return launch_dense<64, 64, 2, 2>(a, vec, s);
+}
+
+int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
+                  const float* h, const float* c, const float* kernel, const float* recurrent,
+                  const float* bias, float* h_out, float* c_out, int N, int C, int E, int H,
+                  int V, hipStream_t s) {
+  ICAP_REQUIRE(ctx && h && c && kernel && recurrent && bias && h_out && c_out,
+               "lstm_step_f32: null pointer");
+  ICAP_REQUIRE((ids && table) || (!ids && emb),
+               "lstm_step_f32: pass either (table, ids) or emb");
+  ICAP_REQUIRE(N > 0 && C > 0 && E > 0 && H > 0, "lstm_step_f32: bad shape");
+  ICAP_REQUIRE(!ids || V > 0, "lstm_step_f32: V must be positive with ids");
+  ICAP_REQUIRE(h_out != h && c_out != h, "lstm_step_f32: outputs must not alias h");
+  LstmArgs a{ctx, emb, table, ids, h, c, kernel, recurrent, bias, h_out, c_out,
+             N, C, E, H, V, ceil_div(N, LSTM_BM), ceil_div(H, LSTM_BJ)};
+  const bool vec = (C % 4 == 0) && (E % 4 == 0) && (H % 4 == 0) && aligned16(ctx) &&
+                   aligned16(ids ? table : emb) && aligned16(h) && aligned16(kernel) &&
+                   aligned16(recurrent);
+  const int grid = a.tiles_m * a.tiles_j;
+  if (vec)
+    hipLaunchKernelGGL(lstm_f32_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(lstm_f32_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+  ICAP_LAUNCH_CHECK("lstm_f32_kernel");
+  return ICAP_OK;
+}
+
+}  // namespace icap

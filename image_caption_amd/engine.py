@@ -1,0 +1,221 @@
+"""Fused whole-sequence decode: the loop of `predict_image_caption_sequence`
+(reference recurrent_example.py:477-562) as one enqueue of HIP kernels on a stream."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+TILE_MODES = {"reference": _lib.TILE_REFERENCE, "repeat": _lib.TILE_REPEAT}
+PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}
+
+# oracle / checkpoint parameter name -> icap_weights field
+PARAM_TO_FIELD = {
+    "enc_kernel": "enc_kernel", "enc_bias": "enc_bias", "embedding": "embedding",
+    "init0_kernel": "init_h_kernel", "init0_bias": "init_h_bias",
+    "init1_kernel": "init_c_kernel", "init1_bias": "init_c_bias",
+    "att_W1_kernel": "att_w1_kernel", "att_W1_bias": "att_w1_bias",
+    "att_W2_kernel": "att_w2_kernel", "att_W2_bias": "att_w2_bias",
+    "att_V_kernel": "att_v_kernel", "att_V_bias": "att_v_bias",
+    "fc3_kernel": "fc3_kernel", "fc3_bias": "fc3_bias",
+    "lstm_kernel": "lstm_kernel", "lstm_recurrent_kernel": "lstm_recurrent_kernel",
+    "lstm_bias": "lstm_bias", "fc1_kernel": "fc1_kernel", "fc1_bias": "fc1_bias",
+    "fc2_kernel": "fc2_kernel", "fc2_bias": "fc2_bias",
+}
+
+
+@dataclass
+class CaptionConfig:
+    """Shapes and decoding constants of one engine (defaults = the reference script:
+    embedding_dim 256, units 512, recurrent_example.py:150-152; tokens start=3, eos=4)."""
+    B: int
+    W: int = 3
+    L: int = 64
+    F: int = 2048
+    D: int = 256
+    E: int = 256
+    H: int = 512
+    U: int = 512
+    V: int = 10000
+    T: int = 20
+    start_id: int = 3
+    eos_id: int = 4
+    length_penalty_weight: float = 1.0
+    reset_state_from_feat: float = 1.0
+    tile_mode: str = "reference"
+    precision: str = "fp32"
+
+    @property
+    def N(self):
+        return self.B * self.W
+
+
+class CaptionEngine:
+    """Owns an icap_engine handle and the device weights it points at."""
+
+    def __init__(self, config: CaptionConfig, params, device=None):
+        if config.tile_mode not in TILE_MODES:
+            raise ValueError("tile_mode must be 'reference' or 'repeat'")
+        if config.precision not in PRECISIONS:
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.config = config
+        self.device = torch.device(device) if device is not None else \
+            torch.device("cuda", torch.cuda.current_device())
+        self._handle = None
+        lib = _lib.load()
+        # device copies of the weights (kept alive by this object)
+        self.weights = {}
+        w = _lib.IcapWeights()
+        for pname, field in PARAM_TO_FIELD.items():
+            if pname not in params:
+                raise KeyError("missing parameter %r" % pname)
+            t = params[pname]
+            if isinstance(t, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            self.weights[field] = t
+            setattr(w, field, t.data_ptr())
+        self._check_shapes()
+        c = _lib.IcapConfig(B=config.B, W=config.W, L=config.L, F=config.F, D=config.D,
+                            E=config.E, H=config.H, U=config.U, V=config.V, T=config.T,
+                            start_id=config.start_id, eos_id=config.eos_id,
+                            tile_mode=TILE_MODES[config.tile_mode],
+                            precision=PRECISIONS[config.precision],
+                            length_penalty_weight=float(config.length_penalty_weight),
+                            reset_state_from_feat=float(config.reset_state_from_feat), reserved=0)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.icap_engine_create(C.byref(c), C.byref(w), C.byref(handle)))
+        self._handle = handle
+
+    def _check_shapes(self):
+        c, w = self.config, self.weights
+        expect = {
+            "enc_kernel": (c.F, c.D), "enc_bias": (c.D,), "embedding": (c.V, c.E),
+            "init_h_kernel": (c.D, c.H), "init_h_bias": (c.H,), "init_c_kernel": (c.D, c.H),
+            "init_c_bias": (c.H,), "att_w1_kernel": (c.D, c.U), "att_w1_bias": (c.U,),
+            "att_w2_kernel": (c.H, c.U), "att_w2_bias": (c.U,), "att_v_kernel": (c.U, 1),
+            "att_v_bias": (1,), "fc3_kernel": (c.H, 1), "fc3_bias": (1,),
+            "lstm_kernel": (c.D + c.E, 4 * c.H), "lstm_recurrent_kernel": (c.H, 4 * c.H),
+            "lstm_bias": (4 * c.H,), "fc1_kernel": (c.H, c.H), "fc1_bias": (c.H,),
+            "fc2_kernel": (c.H, c.V), "fc2_bias": (c.V,)}
+        for k, shape in expect.items():
+            if tuple(w[k].shape) != shape:
+                raise ValueError("weight %s has shape %s, expected %s" % (k, tuple(w[k].shape), shape))
+
+    def close(self):
+        if self._handle is not None:
+            _lib.load().icap_engine_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(_lib.load().icap_engine_workspace_bytes(self._handle))
+
+    def decode(self, img, out=None, scores=None):
+        """img [B,L,F] float32 on the engine's device -> (tokens [B,T] int32, scores [B])."""
+        c = self.config
+        if tuple(img.shape) != (c.B, c.L, c.F):
+            raise ValueError("img must have shape %s" % ((c.B, c.L, c.F),))
+        if out is None:
+            out = torch.empty(c.B, c.T, dtype=torch.int32, device=self.device)
+        if scores is None:
+            scores = torch.empty(c.B, dtype=torch.float32, device=self.device)
+        _lib.call("icap_decode", self._handle, ops._chk(img, torch.float32, "img"),
+                  ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
+                  ops.current_stream())
+        return out, scores
+
+    def trace(self):
+        """Per-step records of the last decode as tensors [T,B,W]: ids, parents (int32),
+        scores, log_probs (float32)."""
+        c = self.config
+        shape = (c.T, c.B, c.W)
+        out = {"ids": torch.empty(shape, dtype=torch.int32, device=self.device),
+               "parents": torch.empty(shape, dtype=torch.int32, device=self.device),
+               "scores": torch.empty(shape, dtype=torch.float32, device=self.device),
+               "log_probs": torch.empty(shape, dtype=torch.float32, device=self.device)}
+        _lib.call("icap_engine_trace", self._handle, out["ids"].data_ptr(),
+                  out["parents"].data_ptr(), out["scores"].data_ptr(),
+                  out["log_probs"].data_ptr(), ops.current_stream())
+        return out
+
+    def set_timing(self, enabled):
+        _lib.call("icap_engine_set_timing", self._handle, 1 if enabled else 0)
+
+    def kernel_times(self):
+        """{kernel class: (total ms, launches)} since timing was enabled."""
+        n = len(_lib.K_NAMES)
+        ms = (C.c_float * n)()
+        cnt = (C.c_int32 * n)()
+        _lib.call("icap_engine_kernel_times", self._handle, ms, cnt)
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.K_NAMES)}
+
+
+def params_from_modules(encoder, decoder):
+    """Collects the device weights of an MlpEncoder + LstmDecoder pair under the
+    engine's parameter names."""
+    from .decoder.embedding import EmbeddingLayer
+    emb = decoder.embedding_layer
+    if not isinstance(emb, EmbeddingLayer):
+        raise TypeError("sequence_beam_search needs decoder.embedding_layer to be an "
+                        "EmbeddingLayer so the engine can read the table")
+    att = decoder.attention
+    return {
+        "enc_kernel": encoder.fc.kernel, "enc_bias": encoder.fc.bias, "embedding": emb.table,
+        "init0_kernel": decoder.feat_proj_state_vec[0].fc.kernel,
+        "init0_bias": decoder.feat_proj_state_vec[0].fc.bias,
+        "init1_kernel": decoder.feat_proj_state_vec[1].fc.kernel,
+        "init1_bias": decoder.feat_proj_state_vec[1].fc.bias,
+        "att_W1_kernel": att.W1.kernel, "att_W1_bias": att.W1.bias,
+        "att_W2_kernel": att.W2.kernel, "att_W2_bias": att.W2.bias,
+        "att_V_kernel": att.V.kernel, "att_V_bias": att.V.bias,
+        "fc3_kernel": decoder.fc3.kernel, "fc3_bias": decoder.fc3.bias,
+        "lstm_kernel": decoder.lstm.kernel,
+        "lstm_recurrent_kernel": decoder.lstm.recurrent_kernel, "lstm_bias": decoder.lstm.bias,
+        "fc1_kernel": decoder.fc1.kernel, "fc1_bias": decoder.fc1.bias,
+        "fc2_kernel": decoder.fc2.kernel, "fc2_bias": decoder.fc2.bias,
+    }
+
+
+_engine_cache = {}
+
+
+def sequence_beam_search(encoder, decoder, img, beam_width, max_len, start_id, eos_id,
+                         length_penalty_weight=1.0, tile_mode="reference", precision="fp32",
+                         return_scores=False):
+    """Whole-sequence beam search with the semantics of the reference driver loop
+    `predict_image_caption_sequence` (recurrent_example.py:477-562).
+
+    img [B,L,F] -> int32 tokens [B,T] (and best-beam scores [B] if asked).  The engine
+    (workspace + weight pointers) is cached per (modules, shapes, constants)."""
+    B, L, F = img.shape
+    if not encoder.fc.built:
+        encoder.fc.build(F, img.device)
+    decoder._build(encoder.fc.units, img.device)
+    p = params_from_modules(encoder, decoder)
+    cfg = CaptionConfig(B=B, W=beam_width, L=L, F=F, D=encoder.fc.units,
+                        E=decoder.embedding_dim, H=decoder.units, U=decoder.attention.units,
+                        V=decoder.vocab_size, T=max_len, start_id=start_id, eos_id=eos_id,
+                        length_penalty_weight=length_penalty_weight,
+                        reset_state_from_feat=float(decoder.reset_state_from_feat),
+                        tile_mode=tile_mode, precision=precision)
+    key = (id(encoder), id(decoder), tuple(sorted(cfg.__dict__.items())),
+           tuple((k, v.data_ptr()) for k, v in sorted(p.items())), str(img.device))
+    eng = _engine_cache.get(key)
+    if eng is None:
+        eng = CaptionEngine(cfg, p, device=img.device)
+        _engine_cache.clear()            # one live engine per call site keeps HBM use flat
+        _engine_cache[key] = eng
+    tokens, scores = eng.decode(img.contiguous())
+    return (tokens, scores) if return_scores else tokens

@@ -1,0 +1,150 @@
+"""Torch-tensor front end of the libicap operators.
+
+torch is used for device memory and streams only: every function checks its
+tensors (ROCm device, dtype, contiguity, shape) and hands raw device pointers plus
+the current HIP stream to the C ABI."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, TILE_REFERENCE, TILE_REPEAT  # noqa: F401
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got device %s)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _chk(t, dtype, name)
+
+
+f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+
+
+def dense(x, kernel, bias=None, act=ACT_NONE, out=None):
+    """act(x . kernel + bias) over the last axis of x."""
+    K, N = kernel.shape
+    if x.shape[-1] != K:
+        raise ValueError("dense: input last dim %d != kernel rows %d" % (x.shape[-1], K))
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=f32, device=x.device)
+    if M:
+        _lib.call("icap_dense_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
+                  _opt(bias, f32, "bias"), _chk(out, f32, "out"), M, K, N, act, current_stream())
+    return out
+
+
+def pool_features(features, mask=None):
+    G, L, D = features.shape
+    out = torch.empty(G, D, dtype=f32, device=features.device)
+    _lib.call("icap_pool_features_f32", _chk(features, f32, "features"), _opt(mask, f32, "mask"),
+              _chk(out, f32, "out"), G, L, D, current_stream())
+    return out
+
+
+def expand_rows(src, W, scale=1.0, tile_mode=TILE_REFERENCE):
+    B, H = src.shape
+    out = torch.empty(B * W, H, dtype=f32, device=src.device)
+    _lib.call("icap_expand_rows_f32", _chk(src, f32, "src"), _chk(out, f32, "out"), B, W, H,
+              float(scale), tile_mode, current_stream())
+    return out
+
+
+def embedding(table, ids):
+    V, E = table.shape
+    ids = ids.reshape(-1)
+    N = ids.numel()
+    out = torch.empty(N, E, dtype=f32, device=table.device)
+    _lib.call("icap_embedding_f32", _chk(table, f32, "table"), _chk(ids, i32, "ids"),
+              _chk(out, f32, "out"), N, V, E, current_stream())
+    return out
+
+
+def attention(pf, features, q, v, bv, score_bias=None, gate_state=None, gate_w=None, gate_b=0.0,
+              rows_per_group=1, row_stride_g=1, row_stride_k=0, want_weights=True):
+    """Returns (ctx[N,D], weights[N,L] or None)."""
+    G, L, U = pf.shape
+    D = features.shape[-1]
+    N = q.shape[0]
+    if features.shape[:2] != (G, L) or q.shape[1] != U or v.numel() != U:
+        raise ValueError("attention: inconsistent shapes")
+    if N != G * rows_per_group:
+        raise ValueError("attention: N must equal G * rows_per_group")
+    H = gate_state.shape[1] if gate_state is not None else 0
+    ctx = torch.empty(N, D, dtype=f32, device=pf.device)
+    weights = torch.empty(N, L, dtype=f32, device=pf.device) if want_weights else None
+    _lib.call("icap_attention_f32", _chk(pf, f32, "pf"), _chk(features, f32, "features"),
+              _chk(q, f32, "q"), _chk(v, f32, "v"), float(bv), _opt(score_bias, f32, "score_bias"),
+              _opt(gate_state, f32, "gate_state"), _opt(gate_w, f32, "gate_w"), float(gate_b),
+              _chk(ctx, f32, "ctx"), _opt(weights, f32, "weights"), G, rows_per_group,
+              row_stride_g, row_stride_k, L, U, D, H, current_stream())
+    return ctx, weights
+
+
+def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, ids=None):
+    """Returns (h', c').  Pass either emb[N,E] or (table[V,E], ids[N])."""
+    N, Cdim = ctx.shape
+    H = h.shape[1]
+    if ids is not None:
+        V, E = table.shape
+        ids = ids.reshape(-1)
+    else:
+        V, E = 0, emb.shape[1]
+    if kernel.shape != (Cdim + E, 4 * H) or recurrent_kernel.shape != (H, 4 * H):
+        raise ValueError("lstm_step: kernel shapes do not match [C+E,4H] / [H,4H]")
+    h_out = torch.empty_like(h)
+    c_out = torch.empty_like(c)
+    _lib.call("icap_lstm_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
+              _opt(table, f32, "table"), _opt(ids, i32, "ids"), _chk(h, f32, "h"),
+              _chk(c, f32, "c"), _chk(kernel, f32, "kernel"),
+              _chk(recurrent_kernel, f32, "recurrent_kernel"), _chk(bias, f32, "bias"),
+              _chk(h_out, f32, "h_out"), _chk(c_out, f32, "c_out"), N, Cdim, E, H, V,
+              current_stream())
+    return h_out, c_out
+
+
+def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_penalty_weight,
+              start_offset=0, input_is_log_prob=False):
+    """Returns (scores, ids, parents, next_log_probs, next_finished(u8), next_lengths)."""
+    B, W, V = logits.shape
+    dev = logits.device
+    scores = torch.empty(B, W, dtype=f32, device=dev)
+    ids = torch.empty(B, W, dtype=i32, device=dev)
+    parents = torch.empty(B, W, dtype=i32, device=dev)
+    nlp = torch.empty(B, W, dtype=f32, device=dev)
+    nfin = torch.empty(B, W, dtype=u8, device=dev)
+    nlen = torch.empty(B, W, dtype=i32, device=dev)
+    _lib.call("icap_beam_step_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
+              _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(time),
+              int(start_offset), int(eos_token), float(length_penalty_weight),
+              1 if input_is_log_prob else 0, scores.data_ptr(), ids.data_ptr(),
+              parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(), B, W, V,
+              current_stream())
+    return scores, ids, parents, nlp, nfin, nlen
+
+
+def backtrack(ids, parents, last_scores, last_finished):
+    """ids/parents [T,B,W] -> (tokens[B,T] i32, best_beam[B] i32, best_score[B] f32)."""
+    T, B, W = ids.shape
+    dev = ids.device
+    tokens = torch.empty(B, T, dtype=i32, device=dev)
+    best = torch.empty(B, dtype=i32, device=dev)
+    best_s = torch.empty(B, dtype=f32, device=dev)
+    _lib.call("icap_backtrack", _chk(ids, i32, "ids"), _chk(parents, i32, "parents"),
+              _chk(last_scores, f32, "last_scores"), _chk(last_finished, u8, "last_finished"),
+              tokens.data_ptr(), best.data_ptr(), best_s.data_ptr(), T, B, W, current_stream())
+    return tokens, best, best_s

@@ -1,0 +1,218 @@
+/*
+ * icap - caption-decoding engine for AMD Instinct MI355X (gfx950).  C ABI.
+ *
+ * This header is the drop-in boundary for the batched show-attend-tell inference
+ * path of king821221/image-caption.  The reference has no FFI of its own (it is
+ * pure Python on TensorFlow eager), so every entry point below names the Python
+ * call site whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (HIP global memory), row-major
+ *     and contiguous unless a leading dimension is given; weights use the Keras
+ *     layouts: Dense.kernel [in,out], LSTMCell.kernel [C+E,4H] /
+ *     recurrent_kernel [H,4H] / bias [4H] with gate order i,f,g,o.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls only
+ *     enqueue work; they never synchronise the stream and never allocate, except
+ *     icap_engine_create / icap_engine_destroy.
+ *   - return value: ICAP_OK (0) or a negative ICAP_ERR_* code; the message is kept
+ *     per host thread and read with icap_last_error().  Nothing throws across the ABI.
+ *   - bool tensors are one byte per element (0/1), ids and lengths are int32.
+ */
+#ifndef ICAP_H_
+#define ICAP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICAP_OK 0
+#define ICAP_ERR_INVALID (-1)     /* bad argument: null pointer, shape, alignment */
+#define ICAP_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define ICAP_ERR_UNSUPPORTED (-3) /* valid request outside the built limits */
+
+#define ICAP_ACT_NONE 0
+#define ICAP_ACT_RELU 1
+
+#define ICAP_TILE_REFERENCE 0 /* row r uses image r % B  (tf.tile, recurrent_example.py:486) */
+#define ICAP_TILE_REPEAT 1    /* row r uses image r / W  (self-consistent layout) */
+
+#define ICAP_PRECISION_FP32 0 /* exact-f32 MFMA everywhere */
+#define ICAP_PRECISION_BF16 1 /* bf16 MFMA for the LSTM-gate and vocab GEMMs, f32 accumulate */
+
+#define ICAP_MAX_BEAM_WIDTH 16
+
+typedef void* icap_stream_t;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int icap_version(void);
+
+/* Copies the calling thread's last error message (NUL terminated, truncated to
+ * `len`) and returns the full message length. */
+size_t icap_last_error(char* buf, size_t len);
+
+/* ---- stateless operators ------------------------------------------------------ */
+
+/* y[M,N] = act(x[M,K] . w[K,N] + bias[N]).  bias may be NULL.
+ * Replaces every tf.keras.layers.Dense on the path: encoder/mlp_encoder.py:17-18
+ * (act = RELU), attention/attention.py:48 (W1, W2), decoder/init_state.py:34,
+ * decoder/lstm_recurrent_decoder.py:106 (fc1) and :112 (fc2). */
+int icap_dense_f32(const float* x, const float* w, const float* bias, float* y,
+                   int M, int K, int N, int act, icap_stream_t stream);
+
+/* pooled[G,D] = mean over L of features[G,L,D]          (mask == NULL)
+ *             = sum over L of features * mask[G,L], 0 where the mask row sums to 0.
+ * Replaces the pooling of FeatureProjState.__call__, decoder/init_state.py:15-32. */
+int icap_pool_features_f32(const float* features, const float* mask, float* pooled,
+                           int G, int L, int D, icap_stream_t stream);
+
+/* dst[N,H] rows <- scale * src[B,H] rows, N = B*W; row r reads image r % B
+ * (ICAP_TILE_REFERENCE) or r / W (ICAP_TILE_REPEAT).  Replaces tf.tile at
+ * recurrent_example.py:486 applied to per-image state, and the
+ * `reset_state_from_feat *` scaling at decoder/lstm_recurrent_decoder.py:129. */
+int icap_expand_rows_f32(const float* src, float* dst, int B, int W, int H,
+                         float scale, int tile_mode, icap_stream_t stream);
+
+/* out[N,E] = table[ids[n], :]; ids outside [0,V) give a zero row.
+ * Replaces EmbeddingLayer.call, decoder/embedding.py:9-10. */
+int icap_embedding_f32(const float* table, const int32_t* ids, float* out,
+                       int N, int V, int E, icap_stream_t stream);
+
+/* Additive attention over L locations, one feature block shared by a group of rows.
+ *   score[n,l] = sum_u v[u] * tanh(pf[g,l,u] + q[n,u]) + bv (+ score_bias[n,l])
+ *   weights[n,:] = softmax_l(score[n,:]);  ctx[n,:] = sum_l weights[n,l] * features[g,l,:]
+ *   if gate_state != NULL: ctx[n,:] *= sigmoid(gate_state[n,:] . gate_w + gate_b)
+ * pf = W1(features) + b1 [G,L,U] (hoisted, step-invariant), q = W2(query) + b2 [N,U].
+ * Group g owns rows n = g*row_stride_g + k*row_stride_k, k in [0, rows_per_group).
+ * Replaces BahdanauAttention.call, attention/attention.py:45-63, and the beta gate
+ * at decoder/lstm_recurrent_decoder.py:93-96.  Requires U % 4 == 0, D % 4 == 0. */
+int icap_attention_f32(const float* pf, const float* features, const float* q,
+                       const float* v, float bv, const float* score_bias,
+                       const float* gate_state, const float* gate_w, float gate_b,
+                       float* ctx, float* weights,
+                       int G, int rows_per_group, int row_stride_g, int row_stride_k,
+                       int L, int U, int D, int H, icap_stream_t stream);
+
+/* One Keras LSTMCell step with the input concatenation and embedding gather fused:
+ *   x = [ctx[n,:C] | emb_n],  emb_n = table[ids[n]] (ids != NULL) or emb[n] (ids == NULL)
+ *   z = x . kernel + h . recurrent_kernel + bias;  i,f,g,o = split(z, 4)
+ *   c' = sig(f)*c + sig(i)*tanh(g);  h' = sig(o)*tanh(c')
+ * c_out may be the same buffer as c (each element is read and written by one thread);
+ * h_out must be a different buffer from h (every workgroup reads all of h).
+ * Replaces tf.concat + tf.keras.layers.LSTMCell at
+ * decoder/lstm_recurrent_decoder.py:100-102 (and embedding.py:10 when ids != NULL). */
+int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
+                       const int32_t* ids, const float* h, const float* c,
+                       const float* kernel, const float* recurrent_kernel,
+                       const float* bias, float* h_out, float* c_out,
+                       int N, int C, int E, int H, int V, icap_stream_t stream);
+
+/* Fused beam-search step for B images x W beams x V words: log-softmax, finished
+ * masking, accumulated log-prob, length penalty, top-W over the flattened W*V
+ * candidates (ties: lower flat index first), gather of log-probs / finished /
+ * lengths by parent beam.  Reads logits once.
+ *   in : logits[B,W,V]; log_probs[B,W] f32; finished[B,W] u8; lengths[B,W] i32
+ *   out: scores[B,W] f32; predicted_ids[B,W] i32; parent_ids[B,W] i32;
+ *        next_log_probs[B,W]; next_finished[B,W]; next_lengths[B,W]
+ * The next_* buffers may be the same buffers as the inputs (in-place update).
+ * time == 0 scores only beam `start_offset` and gathers from beam 0, as the
+ * reference does.  input_is_log_prob != 0 skips the log-softmax (custom prob_fn).
+ * Replaces beam_search_step_batch, beam_search/beam_search.py:360-543 (with
+ * mask_probs :165-197, hyp_score :131-141, choose_top_k :144-148, batch_gather
+ * :347-358).  Requires 1 <= W <= ICAP_MAX_BEAM_WIDTH and W <= V. */
+int icap_beam_step_f32(const float* logits, const float* log_probs,
+                       const uint8_t* finished, const int32_t* lengths,
+                       int time, int start_offset, int eos_token,
+                       double length_penalty_weight, int input_is_log_prob,
+                       float* scores, int32_t* predicted_ids, int32_t* parent_ids,
+                       float* next_log_probs, uint8_t* next_finished,
+                       int32_t* next_lengths, int B, int W, int V,
+                       icap_stream_t stream);
+
+/* Back-tracking over T recorded steps: pick the best final beam per image
+ * (unfinished beams get -1e9 when any beam of the image is finished, first max
+ * wins), then follow parents backwards.  ids/parents are [T,B,W]; tokens is [B,T].
+ * best_beam[B] and best_score[B] may be NULL.
+ * Replaces loc_optimal_beam_path_batch, beam_search/beam_search.py:545-613. */
+int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
+                   const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,
+                   float* best_score, int T, int B, int W, icap_stream_t stream);
+
+/* ---- fused whole-sequence engine ---------------------------------------------- */
+
+typedef struct icap_config {
+  int32_t B, W, L, F, D, E, H, U, V, T; /* D = encoder/context dim, U = attention units */
+  int32_t start_id, eos_id;
+  int32_t tile_mode;            /* ICAP_TILE_* */
+  int32_t precision;            /* ICAP_PRECISION_* */
+  double length_penalty_weight; /* a double: 6^w is folded in double, beam_search.py:127 */
+  float reset_state_from_feat;  /* decoder/lstm_recurrent_decoder.py:129 */
+  int32_t reserved;
+} icap_config;
+
+typedef struct icap_weights { /* device pointers; must outlive the engine */
+  const float* enc_kernel;  const float* enc_bias;        /* [F,D], [D]   */
+  const float* embedding;                                 /* [V,E]        */
+  const float* init_h_kernel; const float* init_h_bias;   /* [D,H], [H]   */
+  const float* init_c_kernel; const float* init_c_bias;   /* [D,H], [H]   */
+  const float* att_w1_kernel; const float* att_w1_bias;   /* [D,U], [U]   */
+  const float* att_w2_kernel; const float* att_w2_bias;   /* [H,U], [U]   */
+  const float* att_v_kernel;  const float* att_v_bias;    /* [U,1], [1]   */
+  const float* fc3_kernel;    const float* fc3_bias;      /* [H,1], [1]   */
+  const float* lstm_kernel;                               /* [D+E,4H]     */
+  const float* lstm_recurrent_kernel;                     /* [H,4H]       */
+  const float* lstm_bias;                                 /* [4H]         */
+  const float* fc1_kernel;    const float* fc1_bias;      /* [H,H], [H]   */
+  const float* fc2_kernel;    const float* fc2_bias;      /* [H,V], [V]   */
+} icap_weights;
+
+typedef struct icap_engine icap_engine;
+
+/* Allocates the workspace for one (device, config) pair on the current device and
+ * reads the scalar biases (att_v_bias, fc3_bias) back once.  One engine serves one
+ * stream at a time; distinct engines are independent. */
+int icap_engine_create(const icap_config* config, const icap_weights* weights,
+                       icap_engine** out);
+int icap_engine_destroy(icap_engine* engine);
+/* Bytes of device workspace the engine holds. */
+size_t icap_engine_workspace_bytes(const icap_engine* engine);
+
+/* Whole-sequence decode: encoder -> tile -> reset_state -> T x (decoder step, beam
+ * step) -> back-track, all enqueued on `stream` without host synchronisation.
+ *   img[B,L,F] f32 -> tokens[B,T] i32 (+ best_score[B] f32, may be NULL)
+ * Replaces predict_image_caption_sequence, recurrent_example.py:477-562. */
+int icap_decode(icap_engine* engine, const float* img, int32_t* tokens,
+                float* best_score, icap_stream_t stream);
+
+/* Copies the per-step records of the last icap_decode into caller buffers (device
+ * pointers, any may be NULL): ids, parents [T,B,W] i32; scores, log_probs [T,B,W] f32
+ * (BeamSearchStepOutput / BeamSearchState.log_probs of every step).  Enqueued on
+ * `stream`, which must be the stream of the decode or ordered after it. */
+int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
+                      float* scores, float* log_probs, icap_stream_t stream);
+
+/* Per-kernel timing with HIP events on the decode stream.  When enabled, every
+ * launch of the decode loop is bracketed by events; icap_engine_kernel_times
+ * synchronises those events and returns, per kernel class, the summed duration in
+ * milliseconds and the launch count since timing was (re-)enabled. */
+#define ICAP_K_ENCODE 0
+#define ICAP_K_FEAT_PROJ 1
+#define ICAP_K_INIT_STATE 2
+#define ICAP_K_ATTN_QUERY 3
+#define ICAP_K_ATTENTION 4
+#define ICAP_K_LSTM 5
+#define ICAP_K_FC1 6
+#define ICAP_K_VOCAB 7
+#define ICAP_K_BEAM 8
+#define ICAP_K_BACKTRACK 9
+#define ICAP_K_COUNT 10
+int icap_engine_set_timing(icap_engine* engine, int enabled);
+int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
+                             int32_t* launches /*[ICAP_K_COUNT]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICAP_H_ */

@@ -1,0 +1,218 @@
+"""Decoder step and whole-sequence decode vs the oracle.
+
+Token ids must be identical to the fp32 oracle.  Both sides are fp32 with different
+summation orders, so a top-k decision whose two candidates are closer than fp32
+noise can legitimately flip; any image whose tokens differ is therefore checked
+against the oracle's own score margins and must be a proven near-tie (relative
+margin below 2e-5), otherwise the test fails.  Log-probs: 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caption_oracle as co
+from tests.helpers import assert_close, dev, np_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(F=24, D=8, E=8, H=12, V=37)
+
+
+def _modules(p, dims, reset=1, device=None):
+    from image_caption_amd.decoder import EmbeddingLayer, LstmDecoder
+    from image_caption_amd.encoder import MlpEncoder
+    d = device or dev()
+    emb = EmbeddingLayer(dims["V"], dims["E"], device=d)
+    enc = MlpEncoder(dims["D"], name="mlp_feature_encoder", device=d)
+    enc.fc.set_weights(p["enc_kernel"], p["enc_bias"], d)
+    dec = LstmDecoder(emb, dims["E"], dims["H"], dims["V"], reset_state_from_feat=reset,
+                      name="target_sequence_decoder", device=d)
+    dec.load_params(p, d)
+    return enc, dec
+
+
+def test_encoder_module_and_training_kwarg():
+    p = co.perturb_biases(co.make_params(0, **SMALL), 1)
+    enc, _ = _modules(p, SMALL)
+    img = co.make_images(2, 3, 5, SMALL["F"])
+    got = np_of(enc(to_dev(img), training=False))
+    assert_close(got, co.mlp_encoder(img, p["enc_kernel"], p["enc_bias"]), what="encoder")
+    with pytest.raises(KeyError):
+        enc(to_dev(img))
+
+
+@pytest.mark.parametrize("dims,N,L", [(SMALL, 6, 5), (dict(F=64, D=256, E=256, H=512, V=1000), 12, 64)])
+def test_decoder_step_module(dims, N, L):
+    p = co.perturb_biases(co.make_params(3, **dims), 4)
+    _, dec = _modules(p, dims)
+    rng = np.random.default_rng(5)
+    feats = np.abs(rng.standard_normal((N, L, dims["D"]))).astype(np.float32)
+    ids = rng.integers(0, dims["V"], size=(N, 1)).astype(np.int32)
+    hidden_o = co.reset_state(p, N, feats, 1)
+    hidden_g = dec.reset_state(torch.zeros(N, 1, device=dev()), {"features": to_dev(feats)})
+    for a, b in zip(hidden_g, hidden_o):
+        assert_close(np_of(a), b, what="reset_state")
+    with pytest.raises(KeyError):
+        dec((to_dev(ids), {"features": to_dev(feats)}, hidden_g))
+    feats_g = to_dev(feats)
+    for step in range(3):
+        lo, hidden_o, wo, co_ = co.lstm_decoder_step(p, ids, feats, hidden_o)
+        lg, hidden_g, wg, cg = dec((to_dev(ids), {"features": feats_g}, hidden_g), training=False)
+        assert tuple(wg.shape) == (N, L, 1) and tuple(lg.shape) == (N, dims["V"])
+        assert_close(np_of(wg), wo, what="weights step %d" % step)
+        assert_close(np_of(cg), co_, what="context step %d" % step)
+        assert_close(np_of(hidden_g[0]), hidden_o[0], rtol=2e-5, what="h step %d" % step)
+        assert_close(np_of(hidden_g[1]), hidden_o[1], rtol=2e-5, what="c step %d" % step)
+        assert_close(np_of(lg), lo, rtol=3e-5, what="logits step %d" % step)
+        ids = np.argmax(lo, axis=1).astype(np.int32)[:, None]
+
+
+def test_decoder_step_with_callable_embedding_and_bias():
+    from image_caption_amd.decoder import EmbeddingLayer, LstmDecoder
+    p = co.perturb_biases(co.make_params(6, **SMALL), 7)
+    emb = EmbeddingLayer(SMALL["V"], SMALL["E"], device=dev())
+    emb.embedding.set_weights(p["embedding"], dev())
+
+    def embedding_lookup(inputs, **kwargs):          # as recurrent_example.py:277-278
+        return emb(inputs)
+
+    dec = LstmDecoder(embedding_lookup, SMALL["E"], SMALL["H"], SMALL["V"],
+                      reset_state_from_feat=1, device=dev())
+    dec.load_params(p, dev())
+    rng = np.random.default_rng(8)
+    N, L = 4, 6
+    feats = np.abs(rng.standard_normal((N, L, SMALL["D"]))).astype(np.float32)
+    bias = rng.standard_normal((N, L)).astype(np.float32)
+    ids = rng.integers(0, SMALL["V"], size=(N, 1)).astype(np.int32)
+    hidden_o = co.reset_state(p, N, feats, 1, bias=np.abs(bias))
+    hidden_g = dec.reset_state(torch.zeros(N, 1), {"features": to_dev(feats),
+                                                   "bias": to_dev(np.abs(bias))})
+    for a, b in zip(hidden_g, hidden_o):
+        assert_close(np_of(a), b, what="masked reset_state")
+    lo, _, wo, _ = co.lstm_decoder_step(p, ids, feats, hidden_o, bias=bias)
+    lg, _, wg, _ = dec((to_dev(ids), {"features": to_dev(feats), "bias": to_dev(bias)}, hidden_g),
+                       training=False)
+    assert_close(np_of(wg), wo, what="weights")
+    assert_close(np_of(lg), lo, rtol=3e-5, what="logits")
+    assert isinstance(dec.copy(), LstmDecoder)
+
+
+def _first_divergence(trace_o, tr_g, b):
+    for t, st in enumerate(trace_o):
+        if (np_of(tr_g["ids"][t, b]) != st["out"].predicted_ids[b]).any() or \
+                (np_of(tr_g["parents"][t, b]) != st["out"].beam_parent_ids[b]).any():
+            return t
+    return None
+
+
+def _oracle_margin(trace_o, t, b, W, V, eos, lpw):
+    """Smallest relative gap around the top-W decision of image b at step t in the oracle."""
+    st = trace_o[t]
+    prev = trace_o[t - 1]["state"] if t > 0 else co.create_initial_beam_state_batch(
+        st["logits"].shape[0], W)
+    one = co.BeamSearchState(prev.log_probs[b:b + 1], prev.finished[b:b + 1], prev.lengths[b:b + 1])
+    cfg = co.BeamSearchConfig(W, V, eos, lpw, lambda s, k: co.choose_top_k(s, min(k + 1, s.shape[-1])))
+    out, _ = co.beam_search_step_batch(t, st["logits"][b:b + 1], one, cfg)
+    s = out.scores[0].astype(np.float64)
+    gaps = np.abs(np.diff(s)) / np.maximum(np.abs(s[:-1]), 1e-30)
+    return float(gaps.min())
+
+
+def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0):
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = co.make_params(seed, **dims)
+    if bias_seed is not None:
+        p = co.perturb_biases(p, bias_seed)
+    img = co.make_images(seed + 50, B, L, dims["F"])
+    tok_o, trace_o = co.predict_image_caption_sequence(p, img, W, T, 3, 4, lpw, tile_mode,
+                                                       return_trace=True)
+    cfg = CaptionConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], E=dims["E"], H=dims["H"],
+                        U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
+                        length_penalty_weight=lpw, tile_mode=tile_mode, **cfg_kw)
+    eng = CaptionEngine(cfg, p, device=dev())
+    tok_g, _ = eng.decode(to_dev(img))
+    tr_g = eng.trace()
+    tok_g = np_of(tok_g)
+    assert tok_g.shape == (B, T) and tok_g.dtype == np.int32
+    bad = [b for b in range(B) if (tok_g[b] != tok_o[b]).any()]
+    explained = []
+    for b in bad:
+        t = _first_divergence(trace_o, tr_g, b)
+        assert t is not None, "image %d: tokens differ but the beam records agree" % b
+        m = _oracle_margin(trace_o, t, b, W, dims["V"], 4, lpw)
+        assert m < 2e-5, "image %d diverges at step %d with oracle margin %.3e" % (b, t, m)
+        explained.append((b, t, m))
+    # log-probs of the images that agree, every step
+    good = [b for b in range(B) if b not in bad]
+    lp_o = np.stack([st["state"].log_probs for st in trace_o])[:, good]
+    sc_o = np.stack([st["out"].scores for st in trace_o])[:, good]
+    ids_o = np.stack([st["out"].predicted_ids for st in trace_o])[:, good]
+    keep = np.array([_first_divergence(trace_o, tr_g, b) is None for b in good])
+    lp_g = np_of(tr_g["log_probs"])[:, good]
+    sc_g = np_of(tr_g["scores"])[:, good]
+    np.testing.assert_array_equal(np_of(tr_g["ids"])[:, good][:, keep], ids_o[:, keep])
+    with np.errstate(over="ignore"):
+        assert_close(np.maximum(lp_g[:, keep], -1e30), np.maximum(lp_o[:, keep], -1e30), rtol=1e-5,
+                     what="log_probs")
+        assert_close(np.maximum(sc_g[:, keep], -1e30), np.maximum(sc_o[:, keep], -1e30), rtol=1e-5,
+                     what="scores")
+    eng.close()
+    return len(bad), explained
+
+
+@pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
+@pytest.mark.parametrize("W", [1, 3])
+def test_decode_small(tile_mode, W):
+    nbad, _ = _compare_decode({}, SMALL, seed=1, B=5, L=5, T=7, W=W, tile_mode=tile_mode,
+                              bias_seed=9)
+    assert nbad == 0
+
+
+def test_decode_length_penalty_and_wide_beam():
+    nbad, _ = _compare_decode({}, dict(F=40, D=16, E=12, H=20, V=101), seed=2, B=4, L=9, T=8,
+                              W=5, tile_mode="repeat", bias_seed=3, lpw=1.2)
+    assert nbad == 0
+
+
+def test_decode_medium_production_dims():
+    dims = dict(F=2048, D=256, E=256, H=512, V=10000)
+    nbad, explained = _compare_decode({}, dims, seed=0, B=16, L=64, T=20, W=3,
+                                      tile_mode="reference")
+    assert nbad <= 1, explained
+
+
+def test_sequence_beam_search_entry_matches_engine():
+    from image_caption_amd import sequence_beam_search
+    p = co.perturb_biases(co.make_params(4, **SMALL), 5)
+    enc, dec = _modules(p, SMALL)
+    img = co.make_images(6, 4, 5, SMALL["F"])
+    tok_o = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4, 1.0, "reference")
+    tok_g = sequence_beam_search(enc, dec, to_dev(img), 3, 6, 3, 4, tile_mode="reference")
+    np.testing.assert_array_equal(np_of(tok_g), tok_o)
+    tok_g2 = sequence_beam_search(enc, dec, to_dev(img), 3, 6, 3, 4, tile_mode="reference")
+    np.testing.assert_array_equal(np_of(tok_g2), tok_o)
+
+
+def test_module_loop_equals_fused_engine():
+    """The reference's own driver loop written against the module API gives the same
+    tokens as the fused engine (same kernels, same order)."""
+    from image_caption_amd import sequence_beam_search
+    from image_caption_amd.beam_search import beam_search as bs
+    p = co.perturb_biases(co.make_params(7, **SMALL), 8)
+    enc, dec = _modules(p, SMALL)
+    B, W, T = 4, 3, 6
+    img = to_dev(co.make_images(9, B, 5, SMALL["F"]))
+    features = enc(img, training=False)
+    features = features.repeat(W, 1, 1)                      # tf.tile(features, [W,1,1])
+    dec_input = torch.full((B * W, 1), 3, dtype=torch.int32, device=dev())
+    hidden = dec.reset_state(torch.zeros_like(dec_input), {"features": features})
+    st = bs.create_initial_beam_state_batch(B, W, device=dev())
+    cfg = bs.BeamSearchConfig(W, SMALL["V"], 4, 1.0, bs.choose_top_k)
+    seq = []
+    for i in range(T):
+        logits, hidden, _, _ = dec((dec_input, {"features": features}, hidden), training=False)
+        out, st = bs.beam_search_step_batch(i, logits.reshape(-1, W, SMALL["V"]), st, cfg)
+        seq.append((out, st))
+        dec_input = out.predicted_ids.reshape(-1, 1)
+    path = torch.cat(bs.loc_optimal_beam_path_batch(seq), dim=1).to(torch.int32)
+    fused = sequence_beam_search(enc, dec, img, W, T, 3, 4, tile_mode="reference")
+    np.testing.assert_array_equal(np_of(path), np_of(fused))
