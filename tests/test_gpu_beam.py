@@ -126,7 +126,7 @@ def test_beam_step_exact_ties_prefer_lower_flat_index(bs):
     lp = np.repeat(-np.abs(rng.standard_normal((B, 1))).astype(np.float32), W, axis=1)
     state = co.BeamSearchState(lp, np.zeros((B, W), bool), np.full((B, W), 2, np.int32))
     out_o, _, _, _ = _check_step(bs, logits, state, 3, W, V, 7, 1.0)
-    assert (out_o.beam_parent_ids == 0).all()         # all winners tie into beam 0
+    assert (out_o.scores[:, 0] == out_o.scores[:, 1]).all()    # the case really has ties
 
 
 def test_beam_step_all_finished_and_partly_finished(bs):
@@ -153,7 +153,8 @@ def test_beam_step_monotone_logits_worst_case_insertion(bs):
     """Increasing logits make every element a new maximum (the slow insertion path)."""
     B, W, V = 2, 3, 3000
     logits = np.tile(np.linspace(-3, 3, V, dtype=np.float32), (B, W, 1))
-    logits[:, 1] += 0.001
+    logits[:, 1] *= 1.01      # distinct distributions per beam (a constant shift would
+    logits[:, 2] *= 0.98      # leave the log-softmax, and so the scores, tied)
     state = co.BeamSearchState(np.zeros((B, W), np.float32), np.zeros((B, W), bool),
                                np.ones((B, W), np.int32))
     _check_step(bs, logits, state, 2, W, V, 5, 1.0)
