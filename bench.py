@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: captions/sec of the whole-sequence beam-search decode
+(beam 3, 20 steps, B=512 images per GPU, fp32) on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path over one batch: encoder -> tile -> reset_state
+-> 20 x (attention, LSTM step, fc1, vocab projection, fused beam step) -> back-track,
+with the synthetic CNN features already resident in HBM.  With N > 1 every rank
+decodes its own 512 images (weak scaling, weights replicated) and the decoded
+sequences are all-gathered over RCCL at the end of every step.
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "beam3_b512_fp32": dict(B=512, W=3, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000, T=20,
+                            precision="fp32"),
+    "greedy_b32_fp32": dict(B=32, W=1, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000, T=20,
+                            precision="fp32"),
+    "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
+                             precision="fp32"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32-input MFMA peak of MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The CPU oracle (op-for-op numpy restatement of the reference loop, including the
+    un-hoisted W1(features) every step) on a bounded sample of the same workload:
+    B=32 images per decode instead of 512, same beam width / dims / steps."""
+    from oracle import caption_oracle as co
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    Bs = 32
+    p = co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"])
+    img = co.make_images(1, Bs, cfg["L"], cfg["F"])
+    co.predict_image_caption_sequence(p, img[:4], cfg["W"], 2, 3, 4)      # warm the BLAS pool
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        co.predict_image_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, 1.0, "reference")
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 50:
+            break
+    return {"value": round(Bs * reps / el, 2), "unit": "captions/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d decodes of B=%d images (beam %d, %d steps, V=%d), numpy oracle, %.1f s"
+                      % (reps, Bs, cfg["W"], cfg["T"], cfg["V"], el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="beam3_b512_fp32", choices=sorted(CONFIGS))
+    ap.add_argument("--tile-mode", default="reference", choices=["reference", "repeat"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from image_caption_amd import synthetic
+    from image_caption_amd.distributed import all_gather_sequences
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = dict(CONFIGS[args.config])
+    precision = cfg.pop("precision")
+    p = synthetic.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"], cfg["U"])
+    ccfg = CaptionConfig(start_id=3, eos_id=4, length_penalty_weight=1.0, tile_mode=args.tile_mode,
+                         precision=precision, **cfg)
+    eng = CaptionEngine(ccfg, p, device=device)
+    img = torch.from_numpy(synthetic.make_images(100 + rank, cfg["B"], cfg["L"], cfg["F"])).to(device)
+    tokens = torch.empty(cfg["B"], cfg["T"], dtype=torch.int32, device=device)
+    scores = torch.empty(cfg["B"], dtype=torch.float32, device=device)
+
+    def step():
+        eng.decode(img, out=tokens, scores=scores)
+        if world > 1:
+            return all_gather_sequences(tokens)
+        return tokens
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    # ---- timed region: exactly `steps` steps.  The launches of the dominant kernel (the
+    # vocab projection) are bracketed by HIP events on the decode stream inside it; they
+    # feed the roofline object. ----
+    eng.set_timing(["vocab"])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    vocab_ms, vocab_n = eng.kernel_times()["vocab"]
+    eng.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[0] == cfg["B"] * world
+
+    # untimed diagnostic pass: every kernel class bracketed (this serialises the stream
+    # around each launch, so it is not part of `value`)
+    eng.set_timing(True)
+    for _ in range(min(args.steps, 5)):
+        step()
+    sync()
+    diag_steps = min(args.steps, 5)
+    ktimes = eng.kernel_times()
+    eng.set_timing(False)
+
+    if rank == 0:
+        N = cfg["B"] * cfg["W"]
+        captions = cfg["B"] * world * args.steps
+        value = captions / elapsed
+        # dominant kernel: the vocab projection  [N,H] x [H,V]  on f32 MFMA
+        n_vocab = vocab_n
+        avg_s = vocab_ms / max(vocab_n, 1) * 1e-3
+        flops = 2.0 * N * cfg["H"] * cfg["V"]
+        achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+        ms_beam, n_beam = ktimes["beam"]
+        ms_att, n_att = ktimes["attention"]
+        beam_gbs = (N * cfg["V"] * 4.0) / (ms_beam / max(n_beam, 1) * 1e-3) / 1e9 if ms_beam else 0
+        att_bytes = cfg["B"] * cfg["L"] * (cfg["U"] + cfg["D"]) * 4.0 + N * (cfg["U"] + cfg["D"] + cfg["L"]) * 4.0
+        att_gbs = att_bytes / (ms_att / max(n_att, 1) * 1e-3) / 1e9 if ms_att else 0
+        line = {
+            "metric": "captions/sec (beam=3, len 20)", "value": round(value, 1),
+            "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "images_per_gpu": cfg["B"], "beam_width": cfg["W"],
+                       "decode_steps": cfg["T"], "locations": cfg["L"], "feature_dim": cfg["F"],
+                       "hidden": cfg["H"], "vocab": cfg["V"], "tile_mode": args.tile_mode,
+                       "sharding": "images split over ranks, all-gather of sequences"},
+            "roofline": {"bound": "mfma", "kernel": "vocab projection dense_f32 [N,H]x[H,V]",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                         "launches": n_vocab},
+            "hbm_kernels": {"beam_step_GBps": round(beam_gbs, 1), "attention_GBps": round(att_gbs, 1),
+                            "peak_GBps": PEAK_HBM_GBS},
+            "kernel_ms_per_step": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

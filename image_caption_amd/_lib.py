@@ -67,7 +67,7 @@ SIGNATURES = {
     "icap_engine_workspace_bytes": ([_P], C.c_size_t),
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
-    "icap_engine_set_timing": ([_P, _I], C.c_int),
+    "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
     "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),
 }
 

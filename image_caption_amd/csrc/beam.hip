@@ -9,7 +9,8 @@
 //           (score, total log-prob, flat index).  A cheap conservative pre-filter on
 //           the un-normalised log-prob skips the IEEE division for almost every
 //           element; survivors are scored exactly as the reference does
-//           ((lp + ((x - max) - lse)) / penalty) and inserted one at a time.
+//           ((lp + ((x - max) - lse)) / penalty) and enter the list best-first by
+//           wave-wide argmax rounds.
 //   merge   the wave lists meet in LDS; wave 0 extracts the W winners in order
 //           (score descending, lower flat index first on ties = tf.nn.top_k) and
 //           writes the outputs and the next beam state.
@@ -59,23 +60,21 @@ struct CandList {
       i[j] = EMPTY_IDX;
     }
   }
-  // true if a candidate with this score (and an index above every listed one)
-  // would enter the list
-  __device__ __forceinline__ bool accepts(float sc) const { return above(sc, WL - 1); }
-  __device__ __forceinline__ bool above(float sc, int j) const {
-    return sc > s[j] || i[j] == EMPTY_IDX;
+  // candidate (sc, ii) ranks ahead of entry j: higher score, or equal score and lower
+  // flat index (the tf.nn.top_k order); an empty slot ranks behind everything
+  __device__ __forceinline__ bool ahead(float sc, int ii, int j) const {
+    return i[j] == EMPTY_IDX || sc > s[j] || (sc == s[j] && ii < i[j]);
   }
-  // insert a candidate whose flat index is larger than every index in the list: it
-  // goes behind every entry with an equal or higher score
+  __device__ __forceinline__ bool accepts(float sc, int ii) const { return ahead(sc, ii, WL - 1); }
   __device__ __forceinline__ void insert(float sc, float tt, int ii) {
 #pragma unroll
     for (int j = WL - 1; j >= 0; --j) {
       const int jm = j > 0 ? j - 1 : 0;
-      if (j > 0 && above(sc, jm)) {
+      if (j > 0 && ahead(sc, ii, jm)) {
         s[j] = s[jm];
         t[j] = t[jm];
         i[j] = i[jm];
-      } else if (above(sc, j)) {
+      } else if (ahead(sc, ii, j)) {
         s[j] = sc;
         t[j] = tt;
         i[j] = ii;
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(BeamArgs p) {
           const float mp = (col == p.eos) ? 0.f : kF32Min;
           const float total = lp + mp;
           const float sc = total / pen;
-          if (list.accepts(sc)) list.insert(sc, total, flat0 + col);
+          if (list.accepts(sc, flat0 + col)) list.insert(sc, total, flat0 + col);
         }
       }
       continue;
@@ -262,25 +261,42 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(BeamArgs p) {
         pass = pass || ((c + e < V) && (tot[e] >= thr));
       }
       if (!__any(pass)) continue;
-      // exact scores, then strict acceptance against the current list tail
+      // Exact scores.  Every element that would enter the list is a contender; each
+      // round moves the wave's best contender into the list (argmax by shuffles), which
+      // raises the bar for the rest, so a batch of 256 elements needs at most WL rounds.
       float sc[4];
-      bool acc = false;
+      bool ok[4];
+      bool any_ok = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pen = (c + e == p.eos) ? pen_eos : pen_oth;
         sc[e] = tot[e] / pen;
-        acc = acc || ((c + e < V) && list.accepts(sc[e]));
+        ok[e] = (c + e < V) && list.accepts(sc[e], flat0 + c + e);
+        any_ok = any_ok || ok[e];
       }
-      unsigned long long mask = __ballot(acc);
-      while (mask) {
-        const int src = __builtin_ctzll(mask);
-        mask &= mask - 1;
+      while (__any(any_ok)) {
+        float bs = -INFINITY, bt = 0.f;
+        int bi = EMPTY_IDX;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ok[e] && cand_better(sc[e], flat0 + c + e, bs, bi)) {
+            bs = sc[e];
+            bt = tot[e];
+            bi = flat0 + c + e;
+          }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float os = __shfl_xor(bs, o, 64);
+          const float ot = __shfl_xor(bt, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (cand_better(os, oi, bs, bi)) { bs = os; bt = ot; bi = oi; }
+        }
+        list.insert(bs, bt, bi);
+        any_ok = false;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float se = __shfl(sc[e], src, 64);
-          const float te = __shfl(tot[e], src, 64);
-          const int col = c0 + src * 4 + e;
-          if (col < V && list.accepts(se)) list.insert(se, te, flat0 + col);
+          ok[e] = ok[e] && (flat0 + c + e != bi) && list.accepts(sc[e], flat0 + c + e);
+          any_ok = any_ok || ok[e];
         }
       }
       refresh_thr();

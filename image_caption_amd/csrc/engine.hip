@@ -65,7 +65,7 @@ struct icap_engine {
   int32_t *len, *hist_ids, *hist_parents, *start_ids;
   uint8_t* fin;
   // timing
-  bool timing = false;
+  unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
   std::vector<Span> spans;
   size_t spans_used = 0;
@@ -107,7 +107,7 @@ struct Timed {
   hipStream_t s;
   bool on;
   size_t idx = 0;
-  Timed(icap_engine* e_, int cls, hipStream_t s_) : e(e_), s(s_), on(e_->timing) {
+  Timed(icap_engine* e_, int cls, hipStream_t s_) : e(e_), s(s_), on(((e_->timing >> cls) & 1u) != 0) {
     if (!on) return;
     if (e->spans_used == e->spans.size()) {
       icap_engine::Span sp;
@@ -120,10 +120,10 @@ struct Timed {
     }
     idx = e->spans_used++;
     e->spans[idx].cls = cls;
-    hipEventRecord(e->spans[idx].a, s);
+    (void)hipEventRecord(e->spans[idx].a, s);
   }
   ~Timed() {
-    if (on) hipEventRecord(e->spans[idx].b, s);
+    if (on) (void)hipEventRecord(e->spans[idx].b, s);
   }
 };
 
@@ -324,7 +324,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   if (err == hipSuccess)
     err = hipMemcpy(&e->fc3_bias, weights->fc3_bias, sizeof(float), hipMemcpyDeviceToHost);
   if (err != hipSuccess) {
-    if (e->ws) hipFree(e->ws);
+    if (e->ws) (void)hipFree(e->ws);
     delete e;
     return fail(ICAP_ERR_HIP, "icap_engine_create: %s", hipGetErrorString(err));
   }
@@ -345,10 +345,10 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
 int icap_engine_destroy(icap_engine* e) {
   if (!e) return ICAP_OK;
   for (auto& sp : e->spans) {
-    hipEventDestroy(sp.a);
-    hipEventDestroy(sp.b);
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
   }
-  if (e->ws) hipFree(e->ws);
+  if (e->ws) (void)hipFree(e->ws);
   delete e;
   return ICAP_OK;
 }
@@ -374,9 +374,9 @@ int icap_engine_trace(const icap_engine* e, int32_t* ids, int32_t* parents, floa
   return ICAP_OK;
 }
 
-int icap_engine_set_timing(icap_engine* e, int enabled) {
+int icap_engine_set_timing(icap_engine* e, unsigned class_mask) {
   ICAP_REQUIRE(e, "icap_engine_set_timing: null engine");
-  e->timing = enabled != 0;
+  e->timing = class_mask;
   e->spans_used = 0;
   return ICAP_OK;
 }

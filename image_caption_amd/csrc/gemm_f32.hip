@@ -32,32 +32,42 @@ struct DenseArgs {
   int tiles_m, tiles_n;
 };
 
-// 16-byte load when the whole vector is in range, element-wise guarded otherwise.
+// Guarded 4-float load without control flow: the address is clamped to `safe` (any
+// readable 16-byte aligned location) when the vector is out of range and the result
+// is zeroed by a select, so the compiler keeps every load of a tile in flight at once
+// (a branch around each load would serialise them behind s_waitcnt vmcnt(0)).
+// VEC: col and ncols are multiples of 4, so a vector is entirely inside or outside.
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ row_ptr, bool row_ok,
-                                        int col, int ncols) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!row_ok) return v;
-  if (VEC && col + 3 < ncols) {
-    v = *reinterpret_cast<const float4*>(row_ptr + col);
-  } else {
-    if (col + 0 < ncols) v.x = row_ptr[col + 0];
-    if (col + 1 < ncols) v.y = row_ptr[col + 1];
-    if (col + 2 < ncols) v.z = row_ptr[col + 2];
-    if (col + 3 < ncols) v.w = row_ptr[col + 3];
+__device__ __forceinline__ float4 load4(const float* __restrict__ row_ptr,
+                                        const float* __restrict__ safe, bool row_ok, int col,
+                                        int ncols) {
+  if (VEC) {
+    const bool ok = row_ok && (col + 3 < ncols);
+    const float4 v = *reinterpret_cast<const float4*>(ok ? row_ptr + col : safe);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  return v;
+  float e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = row_ok && (col + i < ncols);
+    const float v = *(ok ? row_ptr + col + i : safe);
+    e[i] = ok ? v : 0.f;
+  }
+  return make_float4(e[0], e[1], e[2], e[3]);
 }
 
-// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so each XCD
-// walks whole columns of tiles (same B panel, all M tiles) before the next column.
-__device__ __forceinline__ bool tile_of_block(int pid, int tiles_m, int tiles_n, int& tm,
+// XCD-aware tile order.  Workgroups b and b+8 share an XCD (and its L2), so the grid
+// index is first remapped so that every XCD owns one contiguous run of tile numbers
+// (bijective for any tile count), and tile numbers walk down a column of tiles (same
+// B panel, successive M tiles) before moving to the next column.
+__device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n, int& tm,
                                               int& tn) {
+  const int total = tiles_m * tiles_n;
+  const int q = total >> 3, r = total & 7;
   const int xcd = pid & 7;
-  const int local = pid >> 3;
-  tm = local % tiles_m;
-  tn = xcd + 8 * (local / tiles_m);
-  return tn < tiles_n;
+  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+  tm = sid % tiles_m;
+  tn = sid / tiles_m;
 }
 
 template <int BM, int BN, int WM, int WN, bool VEC>
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
   __shared__ float Bs[2][BK][BN];
 
   int tile_m, tile_n;
-  if (!tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n)) return;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
       const int kq = f % (BK / 4);
       const int row = f / (BK / 4);
       const int gm = m0 + row;
-      ra[i] = load4<VEC>(p.A + (size_t)gm * p.lda, gm < p.M, k0 + 4 * kq, p.K);
+      ra[i] = load4<VEC>(p.A + (size_t)gm * p.lda, p.A, gm < p.M, k0 + 4 * kq, p.K);
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
       const int cg = f % (BN / 4);
       const int k = f / (BN / 4);
       const int gk = k0 + k;
-      rb[i] = load4<VEC>(p.B + (size_t)gk * p.ldb, gk < p.K, n0 + 4 * cg, p.N);
+      rb[i] = load4<VEC>(p.B + (size_t)gk * p.ldb, p.B, gk < p.K, n0 + 4 * cg, p.N);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -215,8 +225,8 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   __shared__ float Bs[2][BK][BN];
   __shared__ int row_src[BM];  // embedding row of each tile row (-1: zero row)
 
-  const int tile_m = blockIdx.x % p.tiles_m;
-  const int tile_j = blockIdx.x / p.tiles_m;
+  int tile_m, tile_j;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_j, tile_m, tile_j);
   const int m0 = tile_m * BM;
   const int j0 = tile_j * LSTM_BJ;
   const int K = p.C + p.E + p.H;
@@ -253,45 +263,46 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   float4 ra[A_LD], rb[B_LD];
   const float* emb_base = p.ids ? p.table : p.emb;
 
-  // A[m][k]: k < C from ctx, k < C+E from the embedding row, else from h.  A float4
-  // never straddles two sources on the VEC path because C and E are multiples of 4.
+  // A[m][k]: k < C from ctx, k < C+E from the embedding row, else from h.  On the VEC
+  // path a float4 never straddles two sources because C and E are multiples of 4.
+  // Branch-free: pick the source pointer with selects, clamp to a safe address when
+  // the element is out of range, zero by select.
+  auto a_elem_ptr = [&](int gm, int src, int k, bool& ok) -> const float* {
+    const bool in_ctx = k < p.C, in_emb = k < CE;
+    ok = (gm < p.N) && (k < K) && (in_ctx || !in_emb || src >= 0);
+    const float* q = in_ctx ? p.ctx + (size_t)gm * p.C + k
+                            : (in_emb ? emb_base + (size_t)(src < 0 ? 0 : src) * p.E + (k - p.C)
+                                      : p.h + (size_t)gm * p.H + (k - CE));
+    return ok ? q : p.ctx;
+  };
   auto load_a4 = [&](int row, int k) -> float4 {
     const int gm = m0 + row;
-    if (gm >= p.N || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int src = row_src[row];
     if (VEC) {
-      if (k < p.C) return *reinterpret_cast<const float4*>(p.ctx + (size_t)gm * p.C + k);
-      if (k < CE) {
-        const int src = row_src[row];
-        if (src < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(emb_base + (size_t)src * p.E + (k - p.C));
-      }
-      return *reinterpret_cast<const float4*>(p.h + (size_t)gm * p.H + (k - CE));
+      bool ok;
+      const float* q = a_elem_ptr(gm, src, k, ok);
+      const float4 v = *reinterpret_cast<const float4*>(q);
+      return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float e[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int kk = k + s;
-      float v = 0.f;
-      if (kk < p.C) {
-        v = p.ctx[(size_t)gm * p.C + kk];
-      } else if (kk < CE) {
-        const int src = row_src[row];
-        v = src < 0 ? 0.f : emb_base[(size_t)src * p.E + (kk - p.C)];
-      } else if (kk < K) {
-        v = p.h[(size_t)gm * p.H + (kk - CE)];
-      }
-      e[s] = v;
+      bool ok;
+      const float* q = a_elem_ptr(gm, src, k + s, ok);
+      const float v = *q;
+      e[s] = ok ? v : 0.f;
     }
     return make_float4(e[0], e[1], e[2], e[3]);
   };
   // B[k][c]: tile column c = gate*32 + jj maps to weight column gate*H + j0 + jj.
   auto load_b4 = [&](int k, int c) -> float4 {
-    if (k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
     const int gate = c / LSTM_BJ;
     const int jj = c % LSTM_BJ;
-    const float* rowp = (k < CE) ? p.kernel + (size_t)k * H4 : p.recurrent + (size_t)(k - CE) * H4;
+    const int kk = k < K ? k : 0;
+    const float* rowp = (kk < CE) ? p.kernel + (size_t)kk * H4
+                                  : p.recurrent + (size_t)(kk - CE) * H4;
     rowp += gate * p.H;
-    return load4<VEC>(rowp, true, j0 + jj, p.H);
+    return load4<VEC>(rowp, p.kernel, k < K, j0 + jj, p.H);
   };
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -369,7 +380,7 @@ int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
   DenseArgs p = a;
   p.tiles_m = ceil_div(p.M, BM);
   p.tiles_n = ceil_div(p.N, BN);
-  const int grid = 8 * ceil_div(p.tiles_n, 8) * p.tiles_m;
+  const int grid = p.tiles_m * p.tiles_n;
   if (vec)
     hipLaunchKernelGGL((dense_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(WM * WN * 64),
                        0, s, p);

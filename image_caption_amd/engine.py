@@ -150,8 +150,18 @@ class CaptionEngine:
                   out["log_probs"].data_ptr(), ops.current_stream())
         return out
 
-    def set_timing(self, enabled):
-        _lib.call("icap_engine_set_timing", self._handle, 1 if enabled else 0)
+    def set_timing(self, kernels):
+        """kernels: True (all classes), False/None (off) or an iterable of class names
+        from _lib.K_NAMES whose launches are bracketed by HIP events."""
+        if kernels is True:
+            mask = (1 << len(_lib.K_NAMES)) - 1
+        elif not kernels:
+            mask = 0
+        else:
+            mask = 0
+            for k in kernels:
+                mask |= 1 << _lib.K_NAMES.index(k)
+        _lib.call("icap_engine_set_timing", self._handle, mask)
 
     def kernel_times(self):
         """{kernel class: (total ms, launches)} since timing was enabled."""

@@ -193,10 +193,11 @@ int icap_decode(icap_engine* engine, const float* img, int32_t* tokens,
 int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
                       float* scores, float* log_probs, icap_stream_t stream);
 
-/* Per-kernel timing with HIP events on the decode stream.  When enabled, every
- * launch of the decode loop is bracketed by events; icap_engine_kernel_times
- * synchronises those events and returns, per kernel class, the summed duration in
- * milliseconds and the launch count since timing was (re-)enabled. */
+/* Per-kernel timing with HIP events on the decode stream.  Launches of every kernel
+ * class whose bit is set in `class_mask` (bit ICAP_K_*) are bracketed by events;
+ * 0 disables timing.  icap_engine_kernel_times synchronises those events and returns,
+ * per kernel class, the summed duration in milliseconds and the launch count since
+ * the mask was last set. */
 #define ICAP_K_ENCODE 0
 #define ICAP_K_FEAT_PROJ 1
 #define ICAP_K_INIT_STATE 2
@@ -208,7 +209,7 @@ int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
 #define ICAP_K_BEAM 8
 #define ICAP_K_BACKTRACK 9
 #define ICAP_K_COUNT 10
-int icap_engine_set_timing(icap_engine* engine, int enabled);
+int icap_engine_set_timing(icap_engine* engine, unsigned class_mask);
 int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
                              int32_t* launches /*[ICAP_K_COUNT]*/);
 
