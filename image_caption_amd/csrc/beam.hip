@@ -1,19 +1,24 @@
 // Fused beam-search step (log-softmax + finished mask + length penalty + top-W over
 // W*V candidates + gathers) and back-tracking.
 //
-// beam_step_f32: one workgroup per image.
-//   pass A  per unfinished beam row: online (max, sum exp) over the V logits; when the
-//           image's W*V logits fit in LDS they are staged there so HBM is read once.
-//   pass C  every wave scans its share of the rows in increasing flat index and keeps
-//           a wave-uniform, register-resident list of its best WL candidates
-//           (score, total log-prob, flat index).  A cheap conservative pre-filter on
-//           the un-normalised log-prob skips the IEEE division for almost every
-//           element; survivors are scored exactly as the reference does
-//           ((lp + ((x - max) - lse)) / penalty) and enter the list best-first by
-//           wave-wide argmax rounds.
-//   merge   the wave lists meet in LDS; wave 0 extracts the W winners in order
-//           (score descending, lower flat index first on ties = tf.nn.top_k) and
-//           writes the outputs and the next beam state.
+// beam_step_f32 is two launches:
+//
+//   beam_row_kernel    one workgroup per (image, beam row).  The row's V logits are
+//       read from HBM ONCE into registers (ITEMS float4 per thread, every load issued
+//       before the first use).  One barrier gives the row max, the log-sum-exp and a
+//       lower bound on the row's WL-th best score (the WL-th largest lane maximum), so
+//       only a handful of "contenders" need the exact arithmetic of the reference
+//       ((lp + ((x - max) - lse)) / penalty with an IEEE division); wave 0 ranks them with
+//       DPP argmax rounds and writes the row's best WL candidates to a small workspace.
+//       The global top-W is a subset of the union of the per-row top-W, so nothing is
+//       lost.  Details at the kernel.
+//   beam_merge_kernel  one wavefront per image: merges the W rows' candidates (and the
+//       synthetic candidates of finished beams, which do not depend on the logits),
+//       extracts the W winners in tf.nn.top_k order (score descending, lower flat
+//       index first) and writes the step outputs and the next beam state.
+//
+// Rows too long for the register budget (V > 65536) take the same kernel with the
+// logits streamed twice.
 #include <math.h>
 
 #include "icap_common.h"
@@ -21,7 +26,8 @@
 namespace icap {
 namespace {
 
-constexpr int PEN_N = 64;  // host-computed length-penalty table entries (len 0..63)
+constexpr int PEN_N = 64;   // host-computed length-penalty table entries (len 0..63)
+constexpr int WL_MAX = 16;  // candidate slots per row in the workspace
 constexpr int EMPTY_IDX = 0x7fffffff;
 
 struct BeamArgs {
@@ -37,6 +43,11 @@ struct BeamArgs {
   uint8_t* next_fin;
   int32_t* next_len;
   int B, W, V;
+  // workspace: per (image,row) statistics, then candidate slots
+  float2* ws_stats;  // [B*W] (max, lse)
+  float* ws_score;   // [B*W*WL_MAX]
+  float* ws_total;   // [B*W*WL_MAX]
+  int* ws_idx;       // [B*W*WL_MAX]
   float lpw;
   float pen_den;
   float pen_table[PEN_N];
@@ -47,42 +58,6 @@ __device__ __forceinline__ float penalty_of(const BeamArgs& p, int len) {
   return powf(5.0f + (float)len, p.lpw) / p.pen_den;
 }
 
-template <int WL>
-struct CandList {
-  float s[WL];
-  float t[WL];
-  int i[WL];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int j = 0; j < WL; ++j) {
-      s[j] = -INFINITY;
-      t[j] = 0.f;
-      i[j] = EMPTY_IDX;
-    }
-  }
-  // candidate (sc, ii) ranks ahead of entry j: higher score, or equal score and lower
-  // flat index (the tf.nn.top_k order); an empty slot ranks behind everything
-  __device__ __forceinline__ bool ahead(float sc, int ii, int j) const {
-    return i[j] == EMPTY_IDX || sc > s[j] || (sc == s[j] && ii < i[j]);
-  }
-  __device__ __forceinline__ bool accepts(float sc, int ii) const { return ahead(sc, ii, WL - 1); }
-  __device__ __forceinline__ void insert(float sc, float tt, int ii) {
-#pragma unroll
-    for (int j = WL - 1; j >= 0; --j) {
-      const int jm = j > 0 ? j - 1 : 0;
-      if (j > 0 && ahead(sc, ii, jm)) {
-        s[j] = s[jm];
-        t[j] = t[jm];
-        i[j] = i[jm];
-      } else if (ahead(sc, ii, j)) {
-        s[j] = sc;
-        t[j] = tt;
-        i[j] = ii;
-      }
-    }
-  }
-};
-
 __device__ __forceinline__ bool cand_better(float sa, int ia, float sb, int ib) {
   // a real candidate always beats an empty slot; otherwise higher score, then lower index
   if (ib == EMPTY_IDX) return ia != EMPTY_IDX;
@@ -90,287 +65,454 @@ __device__ __forceinline__ bool cand_better(float sa, int ia, float sb, int ib) 
   return sa > sb || (sa == sb && ia < ib);
 }
 
-template <int NT, int WL, bool VEC>
-__global__ __launch_bounds__(NT) void beam_step_kernel(BeamArgs p) {
-  constexpr int NWV = NT / 64;
-  constexpr bool STAGE = (NT == 1024);  // the image's logits are staged in LDS
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // carve (all offsets multiples of 16 bytes)
-  float* s_lp = reinterpret_cast<float*>(smem);            // [16]
-  float* s_max = s_lp + 16;                                // [16]
-  float* s_lse = s_max + 16;                               // [16]
-  int* s_len = reinterpret_cast<int*>(s_lse + 16);         // [16]
-  int* s_fin = s_len + 16;                                 // [16]
-  float* s_red = reinterpret_cast<float*>(s_fin + 16);     // [2][NWV]
-  float* s_cs = s_red + 2 * NWV + ((2 * NWV) % 4 ? 4 - (2 * NWV) % 4 : 0);  // [NWV*WL]
-  float* s_ct = s_cs + NWV * WL + ((NWV * WL) % 4 ? 4 - (NWV * WL) % 4 : 0);
-  int* s_ci = reinterpret_cast<int*>(s_ct + NWV * WL + ((NWV * WL) % 4 ? 4 - (NWV * WL) % 4 : 0));
-  float* s_logits = reinterpret_cast<float*>(s_ci + NWV * WL + ((NWV * WL) % 4 ? 4 - (NWV * WL) % 4 : 0));
+// wave-wide argmax of (score, total, idx) in tf.nn.top_k order; every lane gets the result.
+// Same DPP ladder as wave_max, carrying the triple; the combine keeps the better of
+// (own, incoming), so lane 63 ends with the best of the wave.
+#define ICAP_BEST_STEP(CTRL, MASK)                                    \
+  {                                                                   \
+    const float os = dpp_f<CTRL, MASK>(-INFINITY, bs);                \
+    const float ot = dpp_f<CTRL, MASK>(0.f, bt);                      \
+    const int oi = dpp_i<CTRL, MASK>(EMPTY_IDX, bi);                  \
+    if (cand_better(os, oi, bs, bi)) { bs = os; bt = ot; bi = oi; }   \
+  }
+__device__ __forceinline__ void wave_best(float& bs, float& bt, int& bi) {
+  ICAP_BEST_STEP(ICAP_DPP_ROW_SHR(1), 0xf)
+  ICAP_BEST_STEP(ICAP_DPP_ROW_SHR(2), 0xf)
+  ICAP_BEST_STEP(ICAP_DPP_ROW_SHR(4), 0xf)
+  ICAP_BEST_STEP(ICAP_DPP_ROW_SHR(8), 0xf)
+  ICAP_BEST_STEP(ICAP_DPP_BCAST15, 0xa)
+  ICAP_BEST_STEP(ICAP_DPP_BCAST31, 0xc)
+  bs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), 63));
+  bt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bt), 63));
+  bi = __builtin_amdgcn_readlane(bi, 63);
+}
 
-  const int b = blockIdx.x;
+// The K largest of the values held one-per-slot by the 64 lanes (PERV slots per lane),
+// largest first, as wave-uniform results; slots are consumed (set to -inf).  Values that
+// are NaN never count.  Returns the K-th largest (-inf if fewer than K exist).
+template <int K, int PERV>
+__device__ __forceinline__ float wave_kth_largest(float (&v)[PERV], int lane, float* out_topk) {
+  float kth = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    float m = v[0];
+#pragma unroll
+    for (int q = 1; q < PERV; ++q) m = fmaxf(m, v[q]);
+    const float top = wave_max(m);
+    kth = top;
+    if (out_topk) out_topk[r] = top;
+    // remove one instance of `top` from its first owner
+    const unsigned long long owners = __ballot(m == top);
+    if (owners != 0 && lane == (int)__builtin_ctzll(owners)) {
+      bool done = false;
+#pragma unroll
+      for (int q = 0; q < PERV; ++q)
+        if (!done && v[q] == top) { v[q] = -INFINITY; done = true; }
+    }
+  }
+  return kth;
+}
+
+// Column of element e of item i for thread tid.  VEC: a thread owns 4 consecutive
+// columns per item (one 16-byte load).  !VEC (V % 4 != 0 or unaligned rows): element
+// (i, e) is its own coalesced 4-byte load, lanes on consecutive columns.
+template <int NT, bool VEC>
+__device__ __forceinline__ int col_of(int i, int e, int tid) {
+  return VEC ? (i * NT + tid) * 4 + e : (i * 4 + e) * NT + tid;
+}
+
+// Loads one item; columns past the end read as -inf (branch-free: clamped address + select).
+template <int NT, bool VEC>
+__device__ __forceinline__ void load_item(const float* __restrict__ row, int i, int tid, int V,
+                                          float (&x)[4]) {
+  if (VEC) {
+    const int c = (i * NT + tid) * 4;
+    const bool ok = c < V;  // V % 4 == 0: all four or none
+    const float4 v = *reinterpret_cast<const float4*>(row + (ok ? c : 0));
+    x[0] = ok ? v.x : -INFINITY;
+    x[1] = ok ? v.y : -INFINITY;
+    x[2] = ok ? v.z : -INFINITY;
+    x[3] = ok ? v.w : -INFINITY;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (i * 4 + e) * NT + tid;
+      const bool ok = c < V;
+      const float v = row[ok ? c : 0];
+      x[e] = ok ? v : -INFINITY;
+    }
+  }
+}
+
+constexpr int LIST_CAP = 256;  // contenders a row can hand to wave 0 through LDS
+
+// One workgroup per (image, beam row).
+//
+// ITEMS > 0: the row fits in registers (V <= NT*4*ITEMS) and is read from memory once.
+// ITEMS == 0: any V; the row is streamed twice (statistics, then contenders).
+//
+// 1. statistics: per-thread (max, sum exp) pairs and the lane maximum over the non-eos
+//    columns; each wave reduces them with DPP and also extracts its WL largest lane
+//    maxima.  One barrier later every thread knows the row max, the log-sum-exp and the
+//    workgroup's WL-th largest lane maximum.  WL distinct elements reach that value, so
+//    it bounds the row's WL-th best score from below: only logits at or above it (less a
+//    few ulps for rounding in the later arithmetic) and the eos column, which has its own
+//    length penalty, can be among the row's best WL.  These are the "contenders" - a
+//    handful out of V.
+// 2. contenders go to a small LDS list; after the second barrier wave 0 computes their
+//    exact scores as the reference does ((lp + ((x - max) - lse)) / penalty, IEEE
+//    division) and extracts the best WL in tf.nn.top_k order with DPP argmax rounds.
+// 3. if the list overflows (massive ties, or fewer than WL finite logits) every wave
+//    joins WL rounds of an exact workgroup-wide argmax instead.
+template <int NT, int ITEMS, int WL, bool VEC>
+__global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
+  constexpr int NWV = NT / 64;
+  constexpr bool CACHED = ITEMS > 0;
+  constexpr int NX = CACHED ? ITEMS : 1;
+  constexpr int PERB = (NWV * WL + 63) / 64;
+  constexpr int PERL = LIST_CAP / 64;
+  __shared__ float s_red[2 * NWV];
+  __shared__ float s_top[64 * PERB];
+  __shared__ float l_x[LIST_CAP];
+  __shared__ int l_c[LIST_CAP];
+  __shared__ int l_n;
+  __shared__ float s_bs[NWV];
+  __shared__ float s_bt[NWV];
+  __shared__ int s_bi[NWV];
+
+  const int W = p.W, V = p.V;
+  const int b = blockIdx.x / W;
+  const int w = blockIdx.x % W;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int W = p.W, V = p.V;
-  const float* lg = p.logits + (size_t)b * W * V;
-
-  if (tid < W) {
-    s_lp[tid] = p.log_probs[(size_t)b * W + tid];
-    s_len[tid] = p.lengths[(size_t)b * W + tid];
-    s_fin[tid] = p.finished[(size_t)b * W + tid] ? 1 : 0;
-  }
-  __syncthreads();
+  const size_t rw = (size_t)b * W + w;
 
   const bool first = p.time <= 0;
-  // rows whose candidates are scored
+  const bool scan = first ? (w == p.start_offset) : true;
+  const bool stats_only = !scan && first && w == 0;  // beam 0 feeds the time-0 log-prob gather
+  if (!scan && !stats_only) return;
+
+  const float* row = p.logits + rw * V;
+  const int n_items = CACHED ? ITEMS : (V + NT * 4 - 1) / (NT * 4);
+
+  // The row loads are issued before the finished flag is looked at, so the flag's
+  // latency is not in front of them (a finished row wastes its reads, nothing else).
+  float xs[NX][4];
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) load_item<NT, VEC>(row, i, tid, V, xs[i]);
+  }
+  if (p.finished[rw]) return;  // candidates of finished beams are made by the merge kernel
+  if (tid == 0) l_n = 0;
+  for (int q = NWV * WL + tid; q < 64 * PERB; q += NT) s_top[q] = -INFINITY;  // unused slots
+
+  // which (item, element) of this thread is the eos column, if any
+  const bool eos_in_row = p.eos >= 0 && p.eos < V;
+  int eos_tid, eos_i, eos_e;
+  if (VEC) { eos_e = p.eos & 3; eos_tid = (p.eos >> 2) % NT; eos_i = (p.eos >> 2) / NT; }
+  else { eos_tid = p.eos % NT; eos_i = (p.eos / NT) >> 2; eos_e = (p.eos / NT) & 3; }
+  const bool eos_mine = eos_in_row && tid == eos_tid;
+
+  // ---- statistics ----
+  float m = -INFINITY, sm = 0.f, lane_max = -INFINITY;
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      m = fmaxf(m, fmaxf(fmaxf(xs[i][0], xs[i][1]), fmaxf(xs[i][2], xs[i][3])));
+    lane_max = m;
+    if (eos_mine) {  // one thread of the row: its lane maximum must leave the eos column out
+      lane_max = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!(i == eos_i && e == eos_e)) lane_max = fmaxf(lane_max, xs[i][e]);
+    }
+    if (!p.input_is_log_prob) {
+      const float mm = (m > -INFINITY) ? m : 0.f;
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        sm += (fast_exp(xs[i][0] - mm) + fast_exp(xs[i][1] - mm)) +
+              (fast_exp(xs[i][2] - mm) + fast_exp(xs[i][3] - mm));
+    }
+  } else {
+    for (int i = 0; i < n_items; ++i) {
+      float x[4];
+      load_item<NT, VEC>(row, i, tid, V, x);
+      const float mn = fmaxf(m, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+      if (!p.input_is_log_prob && mn > -INFINITY) {
+        sm = sm * fast_exp(m - mn) + (fast_exp(x[0] - mn) + fast_exp(x[1] - mn)) +
+             (fast_exp(x[2] - mn) + fast_exp(x[3] - mn));
+      }
+      m = mn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(eos_mine && i == eos_i && e == eos_e)) lane_max = fmaxf(lane_max, x[e]);
+    }
+  }
+  {
+    const float mw = wave_max(m);
+    const float sw = wave_sum((m > -INFINITY) ? sm * fast_exp(m - mw) : 0.f);
+    float lm[1] = {lane_max};
+    float topk[WL];
+    wave_kth_largest<WL, 1>(lm, lane, topk);
+    if (lane == 0) {
+      s_red[wave] = mw;
+      s_red[NWV + wave] = sw;
+#pragma unroll
+      for (int r = 0; r < WL; ++r) s_top[wave * WL + r] = topk[r];
+    }
+  }
+  __syncthreads();
+  float mx = 0.f, lse = 0.f;
+  if (!p.input_is_log_prob) {
+    mx = s_red[0];
+#pragma unroll
+    for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, s_red[i]);
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i)
+      tot += (s_red[i] > -INFINITY) ? s_red[NWV + i] * fast_exp(s_red[i] - mx) : 0.f;
+    lse = logf(tot);
+  }
+  if (tid == 0) p.ws_stats[rw] = make_float2(mx, lse);
+  if (stats_only) return;
+
+  const float lp = p.log_probs[rw];
+  const int len = p.lengths[rw];
+  const int flat0 = first ? 0 : w * V;
+  const float pen_eos = penalty_of(p, len);
+  const float pen_oth = penalty_of(p, len + 1);
+  // un-normalised total log-prob of logit x, exactly as the reference computes it
+  auto total_of = [&](float x) -> float {
+    const float pr = p.input_is_log_prob ? x : (x - mx) - lse;
+    return lp + pr;
+  };
+
+  // ---- bound and contender threshold (in logit space) ----
+  float thr_x;
+  {
+    float tv[PERB];
+#pragma unroll
+    for (int q = 0; q < PERB; ++q) tv[q] = s_top[lane + 64 * q];
+    const float bound_x = wave_kth_largest<WL, PERB>(tv, lane, nullptr);
+    // Two logits closer than a few ulps of the total can collide after the additions and
+    // the division; the slack keeps every element that could tie with the bound.
+    const float bound_t = total_of(bound_x);
+    thr_x = bound_x - ((fabsf(bound_t) + fabsf(bound_x)) * 9.6e-7f + 1e-37f);
+    if (!(thr_x == thr_x)) thr_x = -INFINITY;
+  }
+
+  // ---- contenders to the LDS list ----
+  auto offer = [&](float x, int c) {
+    const int pos = atomicAdd(&l_n, 1);
+    if (pos < LIST_CAP) { l_x[pos] = x; l_c[pos] = c; }
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const bool any4 = (xs[i][0] >= thr_x) || (xs[i][1] >= thr_x) || (xs[i][2] >= thr_x) ||
+                        (xs[i][3] >= thr_x) || (eos_mine && i == eos_i);
+      if (any4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = col_of<NT, VEC>(i, e, tid);
+          if (c < V && (xs[i][e] >= thr_x || c == p.eos)) offer(xs[i][e], c);
+        }
+      }
+    }
+  } else {
+    for (int i = 0; i < n_items; ++i) {
+      float x[4];
+      load_item<NT, VEC>(row, i, tid, V, x);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = col_of<NT, VEC>(i, e, tid);
+        if (c < V && (x[e] >= thr_x || c == p.eos)) offer(x[e], c);
+      }
+    }
+  }
+  __syncthreads();
+  const int n_list = l_n;
+
+  float my_s = -INFINITY, my_t = 0.f;
+  int my_i = EMPTY_IDX;
+  if (n_list <= LIST_CAP) {
+    // ---- common case: wave 0 ranks the listed contenders exactly ----
+    if (wave != 0) return;
+    float cs[PERL], ct[PERL];
+    int ci[PERL];
+#pragma unroll
+    for (int q = 0; q < PERL; ++q) {
+      const int j = lane + 64 * q;
+      cs[q] = -INFINITY;
+      ct[q] = 0.f;
+      ci[q] = EMPTY_IDX;
+      if (j < n_list) {
+        const int c = l_c[j];
+        ct[q] = total_of(l_x[j]);
+        cs[q] = ct[q] / ((c == p.eos) ? pen_eos : pen_oth);
+        ci[q] = flat0 + c;
+      }
+    }
+    for (int r = 0; r < WL; ++r) {
+      float bs = cs[0], bt = ct[0];
+      int bi = ci[0];
+#pragma unroll
+      for (int q = 1; q < PERL; ++q)
+        if (cand_better(cs[q], ci[q], bs, bi)) { bs = cs[q]; bt = ct[q]; bi = ci[q]; }
+      wave_best(bs, bt, bi);
+#pragma unroll
+      for (int q = 0; q < PERL; ++q)
+        if (ci[q] == bi && bi != EMPTY_IDX) { cs[q] = -INFINITY; ci[q] = EMPTY_IDX; }
+      if (lane == r) { my_s = bs; my_t = bt; my_i = bi; }
+    }
+  } else {
+    // ---- overflow: exact workgroup-wide argmax rounds over the whole row ----
+    float last_s = INFINITY;
+    int last_i = -1;  // the previous winner; eligible elements rank strictly behind it
+    for (int r = 0; r < WL; ++r) {
+      float bs = -INFINITY, bt = 0.f;
+      int bi = EMPTY_IDX;
+      auto consider = [&](float x, int c) {
+        if (c >= V) return;
+        const float t = total_of(x);
+        const float sc = t / ((c == p.eos) ? pen_eos : pen_oth);
+        const int fi = flat0 + c;
+        const bool eligible = (last_i < 0) || sc < last_s || (sc == last_s && fi > last_i);
+        if (eligible && cand_better(sc, fi, bs, bi)) { bs = sc; bt = t; bi = fi; }
+      };
+      // the row is re-read from memory (cache-hot) so this rare path stays small
+      const int n_rounds = (V + NT * 4 - 1) / (NT * 4);
+      for (int i = 0; i < n_rounds; ++i) {
+        float x[4];
+        load_item<NT, VEC>(row, i, tid, V, x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) consider(x[e], col_of<NT, VEC>(i, e, tid));
+      }
+      wave_best(bs, bt, bi);
+      if (lane == 0) { s_bs[wave] = bs; s_bt[wave] = bt; s_bi[wave] = bi; }
+      __syncthreads();
+      bs = s_bs[0]; bt = s_bt[0]; bi = s_bi[0];
+#pragma unroll
+      for (int q = 1; q < NWV; ++q)
+        if (cand_better(s_bs[q], s_bi[q], bs, bi)) { bs = s_bs[q]; bt = s_bt[q]; bi = s_bi[q]; }
+      __syncthreads();
+      if (bi == EMPTY_IDX) break;  // fewer than WL candidates in the row
+      last_s = bs;
+      last_i = bi;
+      if (tid == r) { my_s = bs; my_t = bt; my_i = bi; }
+    }
+    if (wave != 0) return;
+  }
+  if (lane < WL) {
+    p.ws_score[rw * WL_MAX + lane] = my_s;
+    p.ws_total[rw * WL_MAX + lane] = my_t;
+    p.ws_idx[rw * WL_MAX + lane] = my_i;
+  }
+}
+
+// One wavefront per image, four images per workgroup.
+template <int WL>
+__global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= p.B) return;
+  const int W = p.W, V = p.V;
+  const bool first = p.time <= 0;
   const int row_lo = first ? p.start_offset : 0;
   const int row_hi = first ? p.start_offset + 1 : W;
 
-  // ---- pass A: per-row (max, lse); stage logits in LDS when they fit ----
-  for (int w = 0; w < W; ++w) {
-    const bool needed = (w >= row_lo && w < row_hi) || (first && w == 0);
-    if (!needed || s_fin[w]) continue;  // block-uniform
-    const float* row = lg + (size_t)w * V;
-    float* srow = s_logits + (size_t)w * V;
-    if (p.input_is_log_prob) {
-      if (STAGE) {
-        for (int c = tid * 4; c < V; c += NT * 4) {
-          if (VEC) {
-            *reinterpret_cast<float4*>(srow + c) = *reinterpret_cast<const float4*>(row + c);
-          } else {
-            for (int e = 0; e < 4 && c + e < V; ++e) srow[c + e] = row[c + e];
-          }
-        }
-      }
-      if (tid == 0) { s_max[w] = 0.f; s_lse[w] = 0.f; }
-      continue;
-    }
-    float m = -INFINITY, s = 0.f;
-#pragma unroll 4
-    for (int c = tid * 4; c < V; c += NT * 4) {
-      float x0, x1, x2, x3;
-      if (VEC) {
-        const float4 x = *reinterpret_cast<const float4*>(row + c);
-        x0 = x.x; x1 = x.y; x2 = x.z; x3 = x.w;
-        if (STAGE) *reinterpret_cast<float4*>(srow + c) = x;
-      } else {
-        x0 = row[c];
-        x1 = c + 1 < V ? row[c + 1] : -INFINITY;
-        x2 = c + 2 < V ? row[c + 2] : -INFINITY;
-        x3 = c + 3 < V ? row[c + 3] : -INFINITY;
-        if (STAGE) {
-          srow[c] = x0;
-          if (c + 1 < V) srow[c + 1] = x1;
-          if (c + 2 < V) srow[c + 2] = x2;
-          if (c + 3 < V) srow[c + 3] = x3;
-        }
-      }
-      const float mn = fmaxf(fmaxf(m, fmaxf(x0, x1)), fmaxf(x2, x3));
-      if (mn > -INFINITY) {
-        s = s * fast_exp(m - mn) + fast_exp(x0 - mn) + fast_exp(x1 - mn) + fast_exp(x2 - mn) +
-            fast_exp(x3 - mn);
-        m = mn;
-      }
-    }
-    // wave then block reduction of (m, s)
-    const float mw = wave_max(m);
-    float sw = (m > -INFINITY) ? s * fast_exp(m - mw) : 0.f;
-    sw = wave_sum(sw);
-    if (lane == 0) { s_red[wave] = mw; s_red[NWV + wave] = sw; }
-    __syncthreads();
-    if (tid == 0) {
-      float mb = -INFINITY;
-      for (int i = 0; i < NWV; ++i) mb = fmaxf(mb, s_red[i]);
-      float sb = 0.f;
-      for (int i = 0; i < NWV; ++i)
-        if (s_red[i] > -INFINITY) sb += s_red[NWV + i] * fast_exp(s_red[i] - mb);
-      s_max[w] = mb;
-      s_lse[w] = logf(sb);
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-
-  // ---- pass C: wave-level candidate lists ----
-  CandList<WL> list;
-  list.init();
-  float thr = -INFINITY;  // conservative bound on `total` below which nothing can enter
-
-  for (int w = row_lo; w < row_hi; ++w) {
-    const float lp = s_lp[w];
-    const int len = s_len[w];
-    const int flat0 = first ? 0 : w * V;
-    if (s_fin[w]) {
-      // Finished beam: masked log-prob is 0 at eos and f32.min elsewhere, whatever the
-      // logits are.  All non-eos candidates tie, so only the first WL+1 columns and
-      // the eos column can ever be selected.  Handled by wave 0 in scan order.
-      if (wave == 0) {
-        const float pen = penalty_of(p, len);
-        const int ncol = min(V, WL + 1);
-        for (int step = 0; step <= ncol; ++step) {
-          int col;
-          if (step < ncol) col = step;
-          else if (p.eos >= ncol && p.eos < V) col = p.eos;
-          else break;
-          const float mp = (col == p.eos) ? 0.f : kF32Min;
-          const float total = lp + mp;
-          const float sc = total / pen;
-          if (list.accepts(sc, flat0 + col)) list.insert(sc, total, flat0 + col);
-        }
-      }
-      continue;
-    }
-    const float mx = s_max[w], lse = s_lse[w];
-    const float pen_eos = penalty_of(p, len);
-    const float pen_oth = penalty_of(p, len + 1);
-    const float* row_g = lg + (size_t)w * V;
-    const float* row_s = s_logits + (size_t)w * V;
-
-    auto refresh_thr = [&]() {
-      if (list.i[WL - 1] == EMPTY_IDX) { thr = -INFINITY; return; }
-      const float tau = list.s[WL - 1];
-      const float a = tau * pen_eos, c = tau * pen_oth;
-      const float lo = fminf(a, c);
-      thr = lo - fabsf(lo) * 4.8e-7f;  // a few ulps of slack; NaN/-inf fall through to exact
-      if (!(thr == thr)) thr = -INFINITY;
-    };
-    refresh_thr();
-
-    for (int c0 = wave * 256; c0 < V; c0 += NWV * 256) {
-      const int c = c0 + lane * 4;
-      float x[4];
-      if (VEC) {
-        if (c < V) {
-          const float4 v4 = STAGE ? *reinterpret_cast<const float4*>(row_s + c)
-                                  : *reinterpret_cast<const float4*>(row_g + c);
-          x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w;
-        } else {
-          x[0] = x[1] = x[2] = x[3] = 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          x[e] = (c + e < V) ? (STAGE ? row_s[c + e] : row_g[c + e]) : 0.f;
-      }
-      float tot[4];
-      bool pass = false;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pr = p.input_is_log_prob ? x[e] : (x[e] - mx) - lse;
-        tot[e] = lp + pr;
-        pass = pass || ((c + e < V) && (tot[e] >= thr));
-      }
-      if (!__any(pass)) continue;
-      // Exact scores.  Every element that would enter the list is a contender; each
-      // round moves the wave's best contender into the list (argmax by shuffles), which
-      // raises the bar for the rest, so a batch of 256 elements needs at most WL rounds.
-      float sc[4];
-      bool ok[4];
-      bool any_ok = false;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pen = (c + e == p.eos) ? pen_eos : pen_oth;
-        sc[e] = tot[e] / pen;
-        ok[e] = (c + e < V) && list.accepts(sc[e], flat0 + c + e);
-        any_ok = any_ok || ok[e];
-      }
-      while (__any(any_ok)) {
-        float bs = -INFINITY, bt = 0.f;
-        int bi = EMPTY_IDX;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (ok[e] && cand_better(sc[e], flat0 + c + e, bs, bi)) {
-            bs = sc[e];
-            bt = tot[e];
-            bi = flat0 + c + e;
-          }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float os = __shfl_xor(bs, o, 64);
-          const float ot = __shfl_xor(bt, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (cand_better(os, oi, bs, bi)) { bs = os; bt = ot; bi = oi; }
-        }
-        list.insert(bs, bt, bi);
-        any_ok = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ok[e] = ok[e] && (flat0 + c + e != bi) && list.accepts(sc[e], flat0 + c + e);
-          any_ok = any_ok || ok[e];
-        }
-      }
-      refresh_thr();
-    }
-  }
-
-  // ---- merge the wave lists ----
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < WL; ++j) {
-      s_cs[wave * WL + j] = list.s[j];
-      s_ct[wave * WL + j] = list.t[j];
-      s_ci[wave * WL + j] = list.i[j];
-    }
-  }
-  __syncthreads();
-  if (wave != 0) return;
-
-  constexpr int NC = NWV * WL;
-  constexpr int PER = (NC + 63) / 64;
+  // candidate slots: row w owns slots [w*(WL+2), (w+1)*(WL+2))
+  constexpr int SLOTS_PER_ROW = WL + 2;
+  constexpr int PER = (WL * SLOTS_PER_ROW + 63) / 64;
   float cs[PER], ct[PER];
   int ci[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int e = lane + 64 * k;
-    cs[k] = e < NC ? s_cs[e] : -INFINITY;
-    ct[k] = e < NC ? s_ct[e] : 0.f;
-    ci[k] = e < NC ? s_ci[e] : EMPTY_IDX;
+    const int slot = lane + 64 * k;
+    const int w = slot / SLOTS_PER_ROW;
+    const int j = slot % SLOTS_PER_ROW;
+    cs[k] = -INFINITY;
+    ct[k] = 0.f;
+    ci[k] = EMPTY_IDX;
+    if (w >= row_lo && w < row_hi) {
+      const size_t rw = (size_t)b * W + w;
+      const int flat0 = first ? 0 : w * V;
+      if (p.finished[rw]) {
+        // Finished beam: the masked log-prob is 0 at eos and f32.min elsewhere whatever
+        // the logits are.  All non-eos candidates tie, so only the first WL+1 columns and
+        // the eos column can ever be selected.
+        const int ncol = min(V, WL + 1);
+        int col = -1;
+        if (j < ncol) col = j;
+        else if (j == ncol && p.eos >= ncol && p.eos < V) col = p.eos;
+        if (col >= 0) {
+          const float total = p.log_probs[rw] + ((col == p.eos) ? 0.f : kF32Min);
+          cs[k] = total / penalty_of(p, p.lengths[rw]);
+          ct[k] = total;
+          ci[k] = flat0 + col;
+        }
+      } else if (j < WL) {
+        cs[k] = p.ws_score[rw * WL_MAX + j];
+        ct[k] = p.ws_total[rw * WL_MAX + j];
+        ci[k] = p.ws_idx[rw * WL_MAX + j];
+      }
+    }
   }
+
+  // W rounds of wave argmax; lane r keeps winner r
+  float my_s = -INFINITY, my_t = 0.f;
+  int my_i = EMPTY_IDX;
   for (int r = 0; r < W; ++r) {
-    // lane-local best, then wave argmax
     float bs = cs[0], bt = ct[0];
     int bi = ci[0];
 #pragma unroll
     for (int k = 1; k < PER; ++k)
       if (cand_better(cs[k], ci[k], bs, bi)) { bs = cs[k]; bt = ct[k]; bi = ci[k]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float os = __shfl_xor(bs, o, 64);
-      const float ot = __shfl_xor(bt, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (cand_better(os, oi, bs, bi)) { bs = os; bt = ot; bi = oi; }
-    }
-    // remove the winner from its owner
+    wave_best(bs, bt, bi);
 #pragma unroll
     for (int k = 0; k < PER; ++k)
       if (ci[k] == bi && bi != EMPTY_IDX) { cs[k] = -INFINITY; ci[k] = EMPTY_IDX; }
-    if (lane == 0) {
-      const size_t o = (size_t)b * W + r;
-      const int flat = (bi == EMPTY_IDX) ? 0 : bi;
-      const int word = flat % V;
-      const int parent = flat / V;
-      float nlp = bt;
-      if (first && p.start_offset != 0) {
-        // reference quirk: the log-prob is gathered from beam 0 at the chosen word
-        const float lp0 = s_lp[0];
-        float pr;
-        if (s_fin[0]) pr = (word == p.eos) ? 0.f : kF32Min;
-        else {
-          const float x = lg[word];
-          pr = p.input_is_log_prob ? x : (x - s_max[0]) - s_lse[0];
-        }
-        nlp = lp0 + pr;
-      }
-      const int pfin = s_fin[parent];
-      const int nfin = (pfin || word == p.eos) ? 1 : 0;
-      const int nlen = s_len[parent] + ((word != p.eos && !nfin) ? 1 : 0);
-      p.scores[o] = bs;
-      p.ids[o] = word;
-      p.parents[o] = parent;
-      p.next_lp[o] = nlp;
-      p.next_fin[o] = (uint8_t)nfin;
-      p.next_len[o] = nlen;
+    if (lane == r) { my_s = bs; my_t = bt; my_i = bi; }
+  }
+
+  // Lanes 0..W-1 finish one winner each.  The next-state buffers may be the state
+  // inputs themselves: one wave owns the image and every load below precedes every
+  // store in program order, so the in-place update is safe.
+  const bool act = lane < W;
+  const size_t o = (size_t)b * W + (act ? lane : 0);
+  const int flat = (my_i == EMPTY_IDX) ? 0 : my_i;
+  const int word = flat % V;
+  const int parent = flat / V;
+  float nlp = my_t;
+  if (first && p.start_offset != 0) {
+    // reference quirk: at time 0 the log-prob is gathered from beam 0 at the chosen word
+    const size_t r0 = (size_t)b * W;
+    float pr;
+    if (p.finished[r0]) {
+      pr = (word == p.eos) ? 0.f : kF32Min;
+    } else {
+      const float x = p.logits[r0 * V + word];
+      const float2 st = p.ws_stats[r0];
+      pr = p.input_is_log_prob ? x : (x - st.x) - st.y;
     }
+    nlp = p.log_probs[r0] + pr;
+  }
+  const size_t rp = (size_t)b * W + parent;
+  const int pfin = p.finished[rp] ? 1 : 0;
+  const int plen = p.lengths[rp];
+  const int nfin = (pfin || word == p.eos) ? 1 : 0;
+  const int nlen = plen + ((word != p.eos && !nfin) ? 1 : 0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // keep the loads above the stores
+  if (act) {
+    p.scores[o] = my_s;
+    p.ids[o] = word;
+    p.parents[o] = parent;
+    p.next_lp[o] = nlp;
+    p.next_fin[o] = (uint8_t)nfin;
+    p.next_len[o] = nlen;
   }
 }
 
@@ -405,53 +547,47 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const int32_t* __restric
   }
 }
 
-constexpr size_t beam_fixed_smem(int nwv, int wl) {
-  auto pad4 = [](size_t n) { return (n + 3) / 4 * 4; };
-  return sizeof(float) * (16 * 5 + pad4(2 * nwv) + 3 * pad4((size_t)nwv * wl));
-}
-
-template <int NT, int WL, bool VEC>
-int launch_beam_v(const BeamArgs& a, size_t smem, hipStream_t s) {
-  // more than 64 KiB of dynamic LDS must be opted into once per kernel
-  static bool opted = false;
-  if (smem > 64 * 1024 && !opted) {
-    ICAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel<NT, WL, VEC>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    opted = true;
-  }
-  hipLaunchKernelGGL((beam_step_kernel<NT, WL, VEC>), dim3(a.B), dim3(NT), smem, s, a);
-  return ICAP_OK;
-}
-
-template <int NT, int WL>
-int launch_beam(const BeamArgs& a, bool vec, size_t smem, hipStream_t s) {
-  const int rc = vec ? launch_beam_v<NT, WL, true>(a, smem, s)
-                     : launch_beam_v<NT, WL, false>(a, smem, s);
-  if (rc != ICAP_OK) return rc;
-  ICAP_LAUNCH_CHECK("beam_step_kernel");
+template <int NT, int ITEMS, int WL>
+int launch_row(const BeamArgs& a, bool vec, hipStream_t s) {
+  const dim3 grid(a.B * a.W), block(NT);
+  if (vec)
+    hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, WL, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, WL, false>), grid, block, 0, s, a);
+  ICAP_LAUNCH_CHECK("beam_row_kernel");
   return ICAP_OK;
 }
 
 template <int WL>
-int dispatch_beam(BeamArgs& a, bool vec, hipStream_t s) {
-  // Stage the image's logits in LDS (one 1024-thread workgroup per CU) when they fit;
-  // otherwise pass C re-reads them through L2 / Infinity Cache with 256-thread groups.
-  const size_t need = (size_t)a.W * a.V * sizeof(float);
-  const size_t fixed_big = beam_fixed_smem(16, WL);
-  if (need + fixed_big <= 150 * 1024) {
-    return launch_beam<1024, WL>(a, vec, fixed_big + need, s);
-  }
-  return launch_beam<256, WL>(a, vec, beam_fixed_smem(4, WL), s);
+int dispatch_beam(const BeamArgs& a, bool vec, hipStream_t s) {
+  int rc;
+  const int V = a.V;
+  if (V <= 256 * 4 * 4) rc = launch_row<256, 4, WL>(a, vec, s);
+  else if (V <= 256 * 4 * 10) rc = launch_row<256, 10, WL>(a, vec, s);
+  else if (V <= 256 * 4 * 16) rc = launch_row<256, 16, WL>(a, vec, s);
+  else if (V <= 1024 * 4 * 13) rc = launch_row<1024, 13, WL>(a, vec, s);
+  else if (V <= 1024 * 4 * 16) rc = launch_row<1024, 16, WL>(a, vec, s);
+  else rc = launch_row<1024, 0, WL>(a, vec, s);  // streamed rows
+  if (rc != ICAP_OK) return rc;
+  hipLaunchKernelGGL(beam_merge_kernel<WL>, dim3(ceil_div(a.B, 4)), dim3(256), 0, s, a);
+  ICAP_LAUNCH_CHECK("beam_merge_kernel");
+  return ICAP_OK;
 }
 
 }  // namespace
+
+size_t beam_step_workspace_bytes(int B, int W) {
+  if (B <= 0 || W <= 0) return 0;
+  const size_t rows = (size_t)B * W;
+  return rows * sizeof(float2) + 3 * rows * WL_MAX * sizeof(float);
+}
 
 int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
                   const int32_t* lengths, int time, int start_offset, int eos_token,
                   double length_penalty_weight, int input_is_log_prob, float* scores,
                   int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
                   uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
-                  hipStream_t s) {
+                  void* workspace, size_t workspace_bytes, hipStream_t s) {
   ICAP_REQUIRE(logits && log_probs && finished && lengths, "beam_step_f32: null input");
   ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
                    next_lengths,
@@ -460,9 +596,14 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   ICAP_REQUIRE(W >= 1 && W <= ICAP_MAX_BEAM_WIDTH, "beam_step_f32: beam width %d outside [1,%d]",
                W, ICAP_MAX_BEAM_WIDTH);
   ICAP_REQUIRE(W <= V, "beam_step_f32: beam width %d exceeds vocab size %d", W, V);
-  ICAP_REQUIRE(start_offset >= 0 && start_offset < W, "beam_step_f32: start_offset %d outside [0,%d)",
-               start_offset, W);
+  ICAP_REQUIRE(start_offset >= 0 && start_offset < W,
+               "beam_step_f32: start_offset %d outside [0,%d)", start_offset, W);
   ICAP_REQUIRE((long long)W * V < (1LL << 31), "beam_step_f32: W*V overflows int32");
+  ICAP_REQUIRE(workspace && aligned16(workspace),
+               "beam_step_f32: workspace must be a 16-byte aligned device pointer");
+  ICAP_REQUIRE(workspace_bytes >= beam_step_workspace_bytes(B, W),
+               "beam_step_f32: workspace of %zu bytes is smaller than the %zu needed",
+               workspace_bytes, beam_step_workspace_bytes(B, W));
   BeamArgs a;
   a.logits = logits; a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
   a.time = time; a.start_offset = start_offset; a.eos = eos_token;
@@ -470,17 +611,20 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   a.scores = scores; a.ids = predicted_ids; a.parents = parent_ids;
   a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
   a.B = B; a.W = W; a.V = V;
+  const size_t rows = (size_t)B * W;
+  char* wsp = static_cast<char*>(workspace);
+  a.ws_stats = reinterpret_cast<float2*>(wsp);
+  a.ws_score = reinterpret_cast<float*>(wsp + rows * sizeof(float2));
+  a.ws_total = a.ws_score + rows * WL_MAX;
+  a.ws_idx = reinterpret_cast<int*>(a.ws_total + rows * WL_MAX);
   // (5 + len)^w in f32, divided by the double 6^w folded to f32: beam_search.py:127-128
   a.lpw = (float)length_penalty_weight;
   a.pen_den = (float)pow(6.0, length_penalty_weight);
   for (int l = 0; l < PEN_N; ++l) a.pen_table[l] = powf(5.0f + (float)l, a.lpw) / a.pen_den;
   const bool vec = (V % 4 == 0) && aligned16(logits);
   if (W <= 1) return dispatch_beam<1>(a, vec, s);
-  if (W <= 2) return dispatch_beam<2>(a, vec, s);
   if (W <= 3) return dispatch_beam<3>(a, vec, s);
-  if (W <= 4) return dispatch_beam<4>(a, vec, s);
   if (W <= 5) return dispatch_beam<5>(a, vec, s);
-  if (W <= 8) return dispatch_beam<8>(a, vec, s);
   if (W <= 10) return dispatch_beam<10>(a, vec, s);
   return dispatch_beam<16>(a, vec, s);
 }

@@ -38,7 +38,8 @@ int expand_rows_f32(const float*, float*, int, int, int, float, int, hipStream_t
 int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
 int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
                   double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
-                  int, hipStream_t);
+                  int, void*, size_t, hipStream_t);
+size_t beam_step_workspace_bytes(int B, int W);
 int backtrack(const int32_t*, const int32_t*, const float*, const uint8_t*, int32_t*, int32_t*,
               float*, int, int, int, hipStream_t);
 
@@ -64,6 +65,8 @@ struct icap_engine {
   float *lp, *hist_scores, *hist_lp;
   int32_t *len, *hist_ids, *hist_parents, *start_ids;
   uint8_t* fin;
+  char* beam_ws;
+  size_t beam_ws_bytes;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
@@ -199,14 +202,15 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       Timed tm(e, ICAP_K_VOCAB, s);
       ICAP_TRY(dense_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N, c.H, c.V, ICAP_ACT_NONE, s));
     }
-    {  // K9: beam step; outputs recorded per step, state updated in place
+    {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
+       // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
-      ICAP_TRY(beam_step_f32(e->logits, e->lp, e->fin, e->len, t, 0, c.eos_id,
+      const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
+      ICAP_TRY(beam_step_f32(e->logits, lp_in, e->fin, e->len, t, 0, c.eos_id,
                              c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
-                             e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N, e->lp,
-                             e->fin, e->len, c.B, c.W, c.V, s));
-      ICAP_HIP(hipMemcpyAsync(e->hist_lp + (size_t)t * N, e->lp, sizeof(float) * N,
-                              hipMemcpyDeviceToDevice, s));
+                             e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
+                             e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W, c.V,
+                             e->beam_ws, e->beam_ws_bytes, s));
     }
   }
   {  // K10
@@ -279,11 +283,14 @@ int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_
                        double length_penalty_weight, int input_is_log_prob, float* scores,
                        int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
                        uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
-                       icap_stream_t stream) {
+                       void* workspace, size_t workspace_bytes, icap_stream_t stream) {
   return beam_step_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
                        length_penalty_weight, input_is_log_prob, scores, predicted_ids, parent_ids,
-                       next_log_probs, next_finished, next_lengths, B, W, V, (hipStream_t)stream);
+                       next_log_probs, next_finished, next_lengths, B, W, V, workspace,
+                       workspace_bytes, (hipStream_t)stream);
 }
+
+size_t icap_beam_step_workspace_bytes(int B, int W) { return beam_step_workspace_bytes(B, W); }
 
 int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
                    const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,
@@ -315,7 +322,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_fc1 = cv.take<float>(N * c.H), o_logits = cv.take<float>(N * c.V),
                o_lp = cv.take<float>(N), o_hs = cv.take<float>(TN), o_hl = cv.take<float>(TN),
                o_len = cv.take<int32_t>(N), o_hi = cv.take<int32_t>(TN),
-               o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N);
+               o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
+               o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W));
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
@@ -338,6 +346,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->len = (int32_t*)(b + o_len); e->hist_ids = (int32_t*)(b + o_hi);
   e->hist_parents = (int32_t*)(b + o_hp); e->start_ids = (int32_t*)(b + o_si);
   e->fin = (uint8_t*)(b + o_fin);
+  e->beam_ws = b + o_bws;
+  e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   *out = e;
   return ICAP_OK;
 }

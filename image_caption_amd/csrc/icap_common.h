@@ -59,15 +59,42 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// Wave64 reductions on DPP (no LDS traffic, ~6 short VALU steps): an inclusive scan by
+// row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast15 / row_bcast31 carry the
+// row totals upward, so lane 63 ends with the reduction of all 64 lanes; v_readlane
+// broadcasts it.  Lanes without a source take `identity` (bound_ctrl off).
+#define ICAP_DPP_ROW_SHR(n) (0x110 + (n))
+#define ICAP_DPP_BCAST15 0x142
+#define ICAP_DPP_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v),
+                                                    CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<ICAP_DPP_ROW_SHR(1), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(2), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(4), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(8), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_BCAST15, 0xa>(0.f, v);
+  v += dpp_f<ICAP_DPP_BCAST31, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(1), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(2), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(4), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(8), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_BCAST15, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_BCAST31, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #endif
 

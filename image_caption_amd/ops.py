@@ -117,6 +117,20 @@ def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, i
     return h_out, c_out
 
 
+_beam_ws = {}
+
+
+def _beam_workspace(B, W, device):
+    """Device scratch for the beam step, cached per (device, stream) and grown on demand."""
+    need = int(_lib.load().icap_beam_step_workspace_bytes(B, W))
+    key = (device, current_stream())
+    ws = _beam_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=device)
+        _beam_ws[key] = ws
+    return ws
+
+
 def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_penalty_weight,
               start_offset=0, input_is_log_prob=False):
     """Returns (scores, ids, parents, next_log_probs, next_finished(u8), next_lengths)."""
@@ -128,12 +142,13 @@ def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_pena
     nlp = torch.empty(B, W, dtype=f32, device=dev)
     nfin = torch.empty(B, W, dtype=u8, device=dev)
     nlen = torch.empty(B, W, dtype=i32, device=dev)
+    ws = _beam_workspace(B, W, dev)
     _lib.call("icap_beam_step_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
               _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(time),
               int(start_offset), int(eos_token), float(length_penalty_weight),
               1 if input_is_log_prob else 0, scores.data_ptr(), ids.data_ptr(),
               parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(), B, W, V,
-              current_stream())
+              ws.data_ptr(), ws.numel(), current_stream())
     return scores, ids, parents, nlp, nfin, nlen
 
 

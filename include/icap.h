@@ -112,7 +112,7 @@ int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
 /* Fused beam-search step for B images x W beams x V words: log-softmax, finished
  * masking, accumulated log-prob, length penalty, top-W over the flattened W*V
  * candidates (ties: lower flat index first), gather of log-probs / finished /
- * lengths by parent beam.  Reads logits once.
+ * lengths by parent beam.  Reads logits once (rows up to 65536 words).
  *   in : logits[B,W,V]; log_probs[B,W] f32; finished[B,W] u8; lengths[B,W] i32
  *   out: scores[B,W] f32; predicted_ids[B,W] i32; parent_ids[B,W] i32;
  *        next_log_probs[B,W]; next_finished[B,W]; next_lengths[B,W]
@@ -121,7 +121,11 @@ int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
  * reference does.  input_is_log_prob != 0 skips the log-softmax (custom prob_fn).
  * Replaces beam_search_step_batch, beam_search/beam_search.py:360-543 (with
  * mask_probs :165-197, hyp_score :131-141, choose_top_k :144-148, batch_gather
- * :347-358).  Requires 1 <= W <= ICAP_MAX_BEAM_WIDTH and W <= V. */
+ * :347-358).  Requires 1 <= W <= ICAP_MAX_BEAM_WIDTH and W <= V.
+ * `workspace` is caller-owned device scratch of at least
+ * icap_beam_step_workspace_bytes(B, W) bytes, 16-byte aligned; its contents need not
+ * be preserved between calls, but two calls that overlap in time need their own. */
+size_t icap_beam_step_workspace_bytes(int B, int W);
 int icap_beam_step_f32(const float* logits, const float* log_probs,
                        const uint8_t* finished, const int32_t* lengths,
                        int time, int start_offset, int eos_token,
@@ -129,7 +133,7 @@ int icap_beam_step_f32(const float* logits, const float* log_probs,
                        float* scores, int32_t* predicted_ids, int32_t* parent_ids,
                        float* next_log_probs, uint8_t* next_finished,
                        int32_t* next_lengths, int B, int W, int V,
-                       icap_stream_t stream);
+                       void* workspace, size_t workspace_bytes, icap_stream_t stream);
 
 /* Back-tracking over T recorded steps: pick the best final beam per image
  * (unfinished beams get -1e9 when any beam of the image is finished, first max
