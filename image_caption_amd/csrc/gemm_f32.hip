@@ -190,10 +190,146 @@ __global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
   }
 }
 
+// Fast path of dense_f32: K % 32 == 0, 16-byte aligned operands, element counts below
+// 2^31.  Out-of-range rows / columns of edge tiles are CLAMPED to valid ones instead of
+// masked (their products land in accumulator rows / columns that are never stored), so
+// the K loop has no masks and no per-iteration address arithmetic: every thread keeps
+// 32-bit element offsets and the tile base pointers advance as scalars.
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(DenseArgs p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_LD = (BM * BK / 4) / NT;
+  constexpr int B_LD = (BK * BN / 4) / NT;
+  constexpr int NG = BK / 8;
+
+  __shared__ float4 As[2][BK / 4][BM + 1];
+  __shared__ float Bs[2][BK][BN];
+
+  int tile_m, tile_n;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  int off_a[A_LD], off_b[B_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int f = tid + i * NT;
+    const int gm = min(m0 + f / (BK / 4), p.M - 1);
+    off_a[i] = gm * p.lda + 4 * (f % (BK / 4));
+  }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int f = tid + i * NT;
+    const int col = min(n0 + 4 * (f % (BN / 4)), p.N - 4);
+    off_b[i] = (f / (BN / 4)) * p.ldb + col;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_LD], rb[B_LD];
+#define ICAP_LOAD_TILES(a_tile_, b_tile_)                                             \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                            \
+      *reinterpret_cast<const float4*>((a_tile_) + off_a[i]);                         \
+  _Pragma("unroll") for (int i = 0; i < B_LD; ++i) rb[i] =                            \
+      *reinterpret_cast<const float4*>((b_tile_) + off_b[i]);
+#define ICAP_STORE_TILES(buf_)                                                        \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                  \
+    const int f = tid + i * NT;                                                       \
+    As[buf_][f % (BK / 4)][f / (BK / 4)] = ra[i];                                     \
+  }                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                  \
+    const int f = tid + i * NT;                                                       \
+    *reinterpret_cast<float4*>(&Bs[buf_][f / (BN / 4)][4 * (f % (BN / 4))]) = rb[i];  \
+  }
+  auto read_frags = [&](int buf, int g, float4 (&a)[TM], float (&b)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * g + half][(wm * TM + i) * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[j][s] = Bs[buf][8 * g + 4 * half + s][(wn * TN + j) * 32 + l31];
+  };
+  auto mfma_group = [&](const float4 (&a)[TM], const float (&b)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j][3], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  const int nk = p.K / BK;
+  const float* a_tile = p.A;
+  const float* b_tile = p.B;
+  ICAP_LOAD_TILES(a_tile, b_tile)
+  ICAP_STORE_TILES(0)
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    // No control flow around the prefetch: the last iteration simply re-loads its own
+    // tile into the idle buffer, which keeps the staging registers out of scratch.
+    const bool more = t + 1 < nk;
+    a_tile += more ? BK : 0;
+    b_tile += more ? (size_t)BK * p.ldb : 0;
+    ICAP_LOAD_TILES(a_tile, b_tile)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 a[TM];
+      float b[TN][4];
+      read_frags(buf, g, a, b);
+      mfma_group(a, b);
+    }
+    ICAP_STORE_TILES(buf ^ 1)
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+          p.C[(size_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
-// LSTM step.  Workgroup = 4 waves stacked along M (32 rows each); every wave owns the
-// four gate tiles (i,f,g,o) of the same 32 hidden units, so the cell update needs no
-// exchange between lanes: register r of the four accumulators is the same (row, unit).
+// LSTM step.  N = B*W rows is small (1536 at the headline shape), so the output is cut
+// into many small units to fill 1024 SIMDs evenly: a workgroup owns 32 rows x 32 hidden
+// units, and its four waves each own ONE gate (i, f, g, o) of that patch - one 32x32
+// accumulator per wave, 768 workgroups = 3 per CU, all resident, so three waves share
+// each SIMD's matrix pipe and cover each other's barriers and LDS waits.  The four gate
+// tiles meet in LDS for the cell update.
 // ---------------------------------------------------------------------------------
 struct LstmArgs {
   const float* ctx;    // [N,C]
@@ -211,19 +347,26 @@ struct LstmArgs {
   int tiles_m, tiles_j;
 };
 
-constexpr int LSTM_BM = 128;
+constexpr int LSTM_BM = 32;
 constexpr int LSTM_BJ = 32;
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   constexpr int NT = 256;
   constexpr int BM = LSTM_BM, BN = 4 * LSTM_BJ;
-  constexpr int A_LD = (BM * BK / 4) / NT;  // 4
-  constexpr int B_LD = (BK * BN / 4) / NT;  // 4
-
-  __shared__ float4 As[2][BK / 4][BM + 1];
-  __shared__ float Bs[2][BK][BN];
+  constexpr int B_LD = (BK * BN / 4) / NT;  // 4 float4 of B per thread per K step (A: 1)
+  constexpr int A_BYTES = 2 * (BK / 4) * (BM + 1) * 16;
+  constexpr int B_BYTES = 2 * BK * BN * 4;
+  constexpr int Z_BYTES = 4 * BM * (LSTM_BJ + 1) * 4;
+  static_assert(Z_BYTES <= A_BYTES + B_BYTES, "gate exchange reuses the staging buffers");
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + B_BYTES];
   __shared__ int row_src[BM];  // embedding row of each tile row (-1: zero row)
+  typedef float4 (*AsT)[BK / 4][BM + 1];
+  typedef float (*BsT)[BK][BN];
+  typedef float (*ZsT)[BM][LSTM_BJ + 1];
+  AsT As = reinterpret_cast<AsT>(smem);
+  BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
+  ZsT Zs = reinterpret_cast<ZsT>(smem);
 
   int tile_m, tile_j;
   tile_of_block(blockIdx.x, p.tiles_m, p.tiles_j, tile_m, tile_j);
@@ -235,7 +378,7 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int gate = tid >> 6;  // wave index = gate
   const int l31 = lane & 31;
   const int half = lane >> 5;
 
@@ -254,13 +397,11 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   }
   __syncthreads();
 
-  f32x16 acc[4];
+  f32x16 acc;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float4 ra[A_LD], rb[B_LD];
+  float4 ra, rb[B_LD];
   const float* emb_base = p.ids ? p.table : p.emb;
 
   // A[m][k]: k < C from ctx, k < C+E from the embedding row, else from h.  On the VEC
@@ -296,20 +437,16 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   };
   // B[k][c]: tile column c = gate*32 + jj maps to weight column gate*H + j0 + jj.
   auto load_b4 = [&](int k, int c) -> float4 {
-    const int gate = c / LSTM_BJ;
+    const int g = c / LSTM_BJ;
     const int jj = c % LSTM_BJ;
     const int kk = k < K ? k : 0;
     const float* rowp = (kk < CE) ? p.kernel + (size_t)kk * H4
                                   : p.recurrent + (size_t)(kk - CE) * H4;
-    rowp += gate * p.H;
+    rowp += g * p.H;
     return load4<VEC>(rowp, p.kernel, k < K, j0 + jj, p.H);
   };
   auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int f = tid + i * NT;
-      ra[i] = load_a4(f / (BK / 4), k0 + 4 * (f % (BK / 4)));
-    }
+    ra = load_a4(tid / (BK / 4), k0 + 4 * (tid % (BK / 4)));
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int f = tid + i * NT;
@@ -317,11 +454,7 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
     }
   };
   auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int f = tid + i * NT;
-      As[buf][f % (BK / 4)][f / (BK / 4)] = ra[i];
-    }
+    As[buf][tid % (BK / 4)][tid / (BK / 4)] = ra;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       const int f = tid + i * NT;
@@ -338,50 +471,61 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
     if (t + 1 < nk) load_tiles((t + 1) * BK);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      const float4 a = As[buf][2 * g + half][wave * 32 + l31];
-      float b[4][4];
+      const float4 a = As[buf][2 * g + half][l31];
+      float b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[j][s] = Bs[buf][8 * g + 4 * half + s][j * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j][0], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j][1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j][2], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j][3], acc[j], 0, 0, 0);
-      }
+      for (int s = 0; s < 4; ++s) b[s] = Bs[buf][8 * g + 4 * half + s][gate * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
     }
     if (t + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
-  const int j = j0 + l31;
-  if (j >= p.H) return;
-  const float bi = p.bias[j], bf = p.bias[p.H + j], bg = p.bias[2 * p.H + j],
-              bo = p.bias[3 * p.H + j];
+  // gate pre-activations (+ bias) to LDS: Zs[gate][row][unit]
+  {
+    const int j = j0 + l31;
+    const float bz = (j < p.H) ? p.bias[gate * p.H + j] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (row < p.N) {
-      const float ig = fast_sigmoid(acc[0][r] + bi);
-      const float fg = fast_sigmoid(acc[1][r] + bf);
-      const float gg = fast_tanh(acc[2][r] + bg);
-      const float og = fast_sigmoid(acc[3][r] + bo);
-      const float c_new = fg * p.c[(size_t)row * p.H + j] + ig * gg;
-      p.c_out[(size_t)row * p.H + j] = c_new;
-      p.h_out[(size_t)row * p.H + j] = og * fast_tanh(c_new);
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      Zs[gate][row][l31] = acc[r] + bz;
+    }
+  }
+  __syncthreads();
+  // cell update: thread owns unit j of rows rb8, rb8+8, rb8+16, rb8+24
+  const int j = j0 + (tid & 31);
+  if (j >= p.H) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (tid >> 5) + 8 * q;
+    const int gm = m0 + row;
+    if (gm < p.N) {
+      const float ig = fast_sigmoid(Zs[0][row][tid & 31]);
+      const float fg = fast_sigmoid(Zs[1][row][tid & 31]);
+      const float gg = fast_tanh(Zs[2][row][tid & 31]);
+      const float og = fast_sigmoid(Zs[3][row][tid & 31]);
+      const float c_new = fg * p.c[(size_t)gm * p.H + j] + ig * gg;
+      p.c_out[(size_t)gm * p.H + j] = c_new;
+      p.h_out[(size_t)gm * p.H + j] = og * fast_tanh(c_new);
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MINW>
 int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
   DenseArgs p = a;
   p.tiles_m = ceil_div(p.M, BM);
   p.tiles_n = ceil_div(p.N, BN);
   const int grid = p.tiles_m * p.tiles_n;
-  if (vec)
+  const bool fast = vec && (p.K % BK == 0) && ((long long)p.M * p.lda < (1LL << 31)) &&
+                    ((long long)p.K * p.ldb < (1LL << 31));
+  if (fast)
+    hipLaunchKernelGGL((dense_f32_fast_kernel<BM, BN, WM, WN, MINW>), dim3(grid),
+                       dim3(WM * WN * 64), 0, s, p);
+  else if (vec)
     hipLaunchKernelGGL((dense_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(WM * WN * 64),
                        0, s, p);
   else
@@ -402,10 +546,11 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
                act);
   DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0};
   const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w);
-  // 128x128 tiles when they fill the chip, 64x64 tiles for the small projections.
+  // 128x128 tiles (8 waves, 32x64 per wave, 2 workgroups = 4 waves per SIMD) when they
+  // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-  if (big_tiles >= 192) return launch_dense<128, 128, 2, 2>(a, vec, s);
-  return launch_dense<64, 64, 2, 2>(a, vec, s);
+  if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 3>(a, vec, s);
+  return launch_dense<64, 64, 2, 2, 2>(a, vec, s);
 }
 
 int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
