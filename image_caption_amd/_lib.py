@@ -58,13 +58,14 @@ SIGNATURES = {
     "icap_embedding_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_attention_f32": ([_P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P,
                             _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
-    "icap_lstm_step_f32": ([_P] * 11 + [_I] * 5 + [_P], C.c_int),
+    "icap_lstm_step_f32": ([_P] * 12 + [_I] * 5 + [_P], C.c_int),
     "icap_beam_step_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                             _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),
     "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
     "icap_engine_create": ([C.POINTER(IcapConfig), C.POINTER(IcapWeights), C.POINTER(_P)], C.c_int),
     "icap_engine_destroy": ([_P], C.c_int),
+    "icap_engine_refresh_weights": ([_P, _P], C.c_int),
     "icap_engine_workspace_bytes": ([_P], C.c_size_t),
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),

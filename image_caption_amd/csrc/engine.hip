@@ -28,8 +28,8 @@ int fail(int code, const char* fmt, ...) {
 // kernels (gemm_f32.hip, attention.hip, beam.hip)
 int dense_f32(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int lstm_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
-                  const float*, const float*, const float*, const float*, float*, float*, int, int,
-                  int, int, int, hipStream_t);
+                  const float*, const float*, const float*, const float*, const float*, float*,
+                  float*, int, int, int, int, int, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, hipStream_t);
@@ -67,6 +67,10 @@ struct icap_engine {
   uint8_t* fin;
   char* beam_ws;
   size_t beam_ws_bytes;
+  float* emb_proj;  // [V,4H] = embedding . lstm_kernel[D:D+E]  (token-only part of the gates)
+  // side stream: the next step's attention runs beside the current step's vocab/beam work
+  hipStream_t side = nullptr;
+  hipEvent_t ev_lstm = nullptr, ev_att = nullptr;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
@@ -174,26 +178,42 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
 
   const int stride_g = c.tile_mode == ICAP_TILE_REPEAT ? c.W : 1;
   const int stride_k = c.tile_mode == ICAP_TILE_REPEAT ? 1 : c.B;
+  // The recurrent state is not reordered by parent beam (recurrent_example.py:526-529),
+  // so the attention of step t+1 depends only on the LSTM of step t, not on the vocab
+  // projection / beam step of step t.  It runs on the side stream beside them:
+  //   main: lstm_t -> fc1_t -> vocab_t -> beam_t -> lstm_{t+1} ...
+  //   side:        \-> query_{t+1} -> attention_{t+1} -/
+  auto attention_step = [&](hipStream_t st) -> int {
+    {  // K4: q = W2(c) + b2      (the query is the LSTM cell state)
+      Timed tm(e, ICAP_K_ATTN_QUERY, st);
+      ICAP_TRY(dense_f32(e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N, c.H, c.U, ICAP_ACT_NONE, st));
+    }
+    {  // K5: additive attention + beta gate
+      Timed tm(e, ICAP_K_ATTENTION, st);
+      ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
+                             e->c, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
+                             stride_k, c.L, c.U, c.D, c.H, st));
+    }
+    return ICAP_OK;
+  };
+  ICAP_TRY(attention_step(s));
   int cur = 0;
   for (int t = 0; t < c.T; ++t) {
     const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
-    {  // K4: q = W2(c) + b2      (the query is the LSTM cell state)
-      Timed tm(e, ICAP_K_ATTN_QUERY, s);
-      ICAP_TRY(dense_f32(e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N, c.H, c.U, ICAP_ACT_NONE, s));
-    }
-    {  // K5: additive attention + beta gate
-      Timed tm(e, ICAP_K_ATTENTION, s);
-      ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
-                             e->c, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
-                             stride_k, c.L, c.U, c.D, c.H, s));
-    }
+    if (t > 0) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
     {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
-      ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->h[cur], e->c, w.lstm_kernel,
-                             w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1], e->c, N, c.D,
-                             c.E, c.H, c.V, s));
+      ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur], e->c,
+                             w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1],
+                             e->c, N, c.D, c.E, c.H, c.V, s));
     }
     cur ^= 1;
+    if (t + 1 < c.T) {
+      ICAP_HIP(hipEventRecord(e->ev_lstm, s));
+      ICAP_HIP(hipStreamWaitEvent(e->side, e->ev_lstm, 0));
+      ICAP_TRY(attention_step(e->side));
+      ICAP_HIP(hipEventRecord(e->ev_att, e->side));
+    }
     {  // K7: fc1
       Timed tm(e, ICAP_K_FC1, s);
       ICAP_TRY(dense_f32(e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N, c.H, c.H, ICAP_ACT_NONE, s));
@@ -228,7 +248,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 100; }
+int icap_version(void) { return 101; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -271,11 +291,11 @@ int icap_attention_f32(const float* pf, const float* features, const float* q, c
 }
 
 int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
-                       const float* h, const float* c, const float* kernel,
+                       const float* emb_proj, const float* h, const float* c, const float* kernel,
                        const float* recurrent_kernel, const float* bias, float* h_out,
                        float* c_out, int N, int C, int E, int H, int V, icap_stream_t stream) {
-  return lstm_step_f32(ctx, emb, table, ids, h, c, kernel, recurrent_kernel, bias, h_out, c_out, N,
-                       C, E, H, V, (hipStream_t)stream);
+  return lstm_step_f32(ctx, emb, table, ids, emb_proj, h, c, kernel, recurrent_kernel, bias, h_out,
+                       c_out, N, C, E, H, V, (hipStream_t)stream);
 }
 
 int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
@@ -323,7 +343,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_lp = cv.take<float>(N), o_hs = cv.take<float>(TN), o_hl = cv.take<float>(TN),
                o_len = cv.take<int32_t>(N), o_hi = cv.take<int32_t>(TN),
                o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
-               o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W));
+               o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
+               o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
@@ -331,7 +352,13 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     err = hipMemcpy(&e->att_v_bias, weights->att_v_bias, sizeof(float), hipMemcpyDeviceToHost);
   if (err == hipSuccess)
     err = hipMemcpy(&e->fc3_bias, weights->fc3_bias, sizeof(float), hipMemcpyDeviceToHost);
+  if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
   if (err != hipSuccess) {
+    if (e->ev_att) (void)hipEventDestroy(e->ev_att);
+    if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
+    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ws) (void)hipFree(e->ws);
     delete e;
     return fail(ICAP_ERR_HIP, "icap_engine_create: %s", hipGetErrorString(err));
@@ -348,8 +375,30 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->fin = (uint8_t*)(b + o_fin);
   e->beam_ws = b + o_bws;
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
+  e->emb_proj = (float*)(b + o_ep);
+  {
+    const int rc = icap_engine_refresh_weights(e, nullptr);
+    if (rc != ICAP_OK) {
+      icap_engine_destroy(e);
+      return rc;
+    }
+    const hipError_t se = hipStreamSynchronize(nullptr);
+    if (se != hipSuccess) {
+      icap_engine_destroy(e);
+      return fail(ICAP_ERR_HIP, "icap_engine_create: %s", hipGetErrorString(se));
+    }
+  }
   *out = e;
   return ICAP_OK;
+}
+
+int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
+  ICAP_REQUIRE(e, "icap_engine_refresh_weights: null engine");
+  const icap_config& c = e->cfg;
+  // emb_proj[v] = embedding[v] . lstm_kernel[D:D+E]: the part of the LSTM gates that
+  // depends only on the input token, hoisted out of the step loop
+  return dense_f32(e->w.embedding, e->w.lstm_kernel + (size_t)c.D * 4 * c.H, nullptr, e->emb_proj,
+                   c.V, c.E, 4 * c.H, ICAP_ACT_NONE, (hipStream_t)stream);
 }
 
 int icap_engine_destroy(icap_engine* e) {
@@ -358,6 +407,9 @@ int icap_engine_destroy(icap_engine* e) {
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);
   }
+  if (e->ev_att) (void)hipEventDestroy(e->ev_att);
+  if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
+  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->ws) (void)hipFree(e->ws);
   delete e;
   return ICAP_OK;

@@ -341,6 +341,7 @@ struct LstmArgs {
   const float* kernel;     // [C+E,4H]
   const float* recurrent;  // [H,4H]
   const float* bias;       // [4H]
+  const float* emb_proj;   // [V,4H] = table . kernel[C:C+E] or null (then E > 0)
   float* h_out;
   float* c_out;
   int N, C, E, H, V;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   float4 ra, rb[B_LD];
-  const float* emb_base = p.ids ? p.table : p.emb;
+  const float* emb_base = p.ids ? p.table : p.emb;  // unused when E == 0 (emb_proj mode)
 
   // A[m][k]: k < C from ctx, k < C+E from the embedding row, else from h.  On the VEC
   // path a float4 never straddles two sources because C and E are multiples of 4.
@@ -484,14 +485,24 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
     __syncthreads();
   }
 
-  // gate pre-activations (+ bias) to LDS: Zs[gate][row][unit]
+  // gate pre-activations (+ bias, + the pre-multiplied embedding row) to LDS:
+  // Zs[gate][row][unit]
   {
     const int j = j0 + l31;
     const float bz = (j < p.H) ? p.bias[gate * p.H + j] : 0.f;
+    float ep[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      Zs[gate][row][l31] = acc[r] + bz;
+      const int src = row_src[row];
+      const bool ok = p.emb_proj != nullptr && src >= 0 && j < p.H;
+      const float v = *(ok ? p.emb_proj + (size_t)src * H4 + gate * p.H + j : p.bias);
+      ep[r] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      Zs[gate][row][l31] = (acc[r] + ep[r]) + bz;
     }
   }
   __syncthreads();
@@ -554,21 +565,25 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
 }
 
 int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
-                  const float* h, const float* c, const float* kernel, const float* recurrent,
-                  const float* bias, float* h_out, float* c_out, int N, int C, int E, int H,
-                  int V, hipStream_t s) {
+                  const float* emb_proj, const float* h, const float* c, const float* kernel,
+                  const float* recurrent, const float* bias, float* h_out, float* c_out, int N,
+                  int C, int E, int H, int V, hipStream_t s) {
   ICAP_REQUIRE(ctx && h && c && kernel && recurrent && bias && h_out && c_out,
                "lstm_step_f32: null pointer");
-  ICAP_REQUIRE((ids && table) || (!ids && emb),
-               "lstm_step_f32: pass either (table, ids) or emb");
+  ICAP_REQUIRE((ids && (table || emb_proj)) || (!ids && emb && !emb_proj),
+               "lstm_step_f32: pass (table, ids), (emb_proj, ids) or emb");
   ICAP_REQUIRE(N > 0 && C > 0 && E > 0 && H > 0, "lstm_step_f32: bad shape");
   ICAP_REQUIRE(!ids || V > 0, "lstm_step_f32: V must be positive with ids");
   ICAP_REQUIRE(h_out != h && c_out != h, "lstm_step_f32: outputs must not alias h");
-  LstmArgs a{ctx, emb, table, ids, h, c, kernel, recurrent, bias, h_out, c_out,
-             N, C, E, H, V, ceil_div(N, LSTM_BM), ceil_div(H, LSTM_BJ)};
+  // With the pre-multiplied embedding the GEMM runs over [ctx | h] only (K = C + H): the
+  // kernel sees E = 0 and adds emb_proj[id] in its epilogue.
+  const int e_gemm = emb_proj ? 0 : E;
+  LstmArgs a{ctx, emb, table, ids, h, c, kernel, recurrent, bias, emb_proj, h_out, c_out,
+             N, C, e_gemm, H, V, ceil_div(N, LSTM_BM), ceil_div(H, LSTM_BJ)};
+  if (emb_proj) a.recurrent = recurrent;  // rows C.. of the B operand come from `recurrent`
   const bool vec = (C % 4 == 0) && (E % 4 == 0) && (H % 4 == 0) && aligned16(ctx) &&
-                   aligned16(ids ? table : emb) && aligned16(h) && aligned16(kernel) &&
-                   aligned16(recurrent);
+                   (emb_proj || aligned16(ids ? table : emb)) && aligned16(h) &&
+                   aligned16(kernel) && aligned16(recurrent);
   const int grid = a.tiles_m * a.tiles_j;
   if (vec)
     hipLaunchKernelGGL(lstm_f32_kernel<true>, dim3(grid), dim3(256), 0, s, a);

@@ -86,6 +86,7 @@ class LstmDecoder(Decoder):
             FeatureProjState(units, '{}/lstmt_feat_proj_{}'.format(self.name, hidx), device=device)
             for hidx in range(self.num_cells)]
         self._fc3_b = None
+        self._emb_proj = None
         self.args = get_kwargs()
 
     # -- lazily built variables (Keras builds on first call) --
@@ -114,6 +115,18 @@ class LstmDecoder(Decoder):
             self._fc3_b = (self.fc3.bias._version, float(self.fc3.bias.item()))
         return self._fc3_b[1]
 
+    def _embedding_projection(self, feat_dim):
+        """[V,4H] = embedding table . lstm kernel rows of the embedding input: the part of
+        the gate pre-activations that depends only on the token, computed once per weight
+        version and gathered by id inside the LSTM kernel."""
+        table = self.embedding_layer.table
+        key = (table.data_ptr(), table._version, self.lstm.kernel.data_ptr(),
+               self.lstm.kernel._version)
+        if self._emb_proj is None or self._emb_proj[0] != key:
+            rows = self.lstm.kernel[feat_dim:feat_dim + self.embedding_dim]
+            self._emb_proj = (key, ops.dense(table, rows.contiguous(), None))
+        return self._emb_proj[1]
+
     def call(self, inputs, **kwargs):
         dec_input, feat_d, hidden = inputs
         features = feat_d['features']
@@ -138,7 +151,8 @@ class LstmDecoder(Decoder):
             h_new, c_new = ops.lstm_step(context_vector, h_prev, c_prev, self.lstm.kernel,
                                          self.lstm.recurrent_kernel, self.lstm.bias,
                                          table=self.embedding_layer.table,
-                                         ids=ids.to(torch.int32))
+                                         ids=ids.to(torch.int32),
+                                         emb_proj=self._embedding_projection(features.shape[-1]))
         else:
             emb = self.embedding_layer(ids, **kwargs)
             emb = emb.reshape(-1, emb.shape[-1]).contiguous()
@@ -192,4 +206,5 @@ class LstmDecoder(Decoder):
             self.embedding_layer.embedding.set_weights(p["embedding"], dev)
         self.attention._pf_key = None
         self._fc3_b = None
+        self._emb_proj = None
         self.attention._bv = None

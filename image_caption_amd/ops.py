@@ -95,13 +95,19 @@ def attention(pf, features, q, v, bv, score_bias=None, gate_state=None, gate_w=N
     return ctx, weights
 
 
-def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, ids=None):
-    """Returns (h', c').  Pass either emb[N,E] or (table[V,E], ids[N])."""
+def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, ids=None,
+              emb_proj=None):
+    """Returns (h', c').  Pass emb[N,E], or ids[N] with table[V,E] and/or the pre-multiplied
+    emb_proj[V,4H] = table . kernel[C:C+E]."""
     N, Cdim = ctx.shape
     H = h.shape[1]
     if ids is not None:
-        V, E = table.shape
         ids = ids.reshape(-1)
+        if emb_proj is not None:
+            V = emb_proj.shape[0]
+            E = kernel.shape[0] - Cdim
+        else:
+            V, E = table.shape
     else:
         V, E = 0, emb.shape[1]
     if kernel.shape != (Cdim + E, 4 * H) or recurrent_kernel.shape != (H, 4 * H):
@@ -109,7 +115,8 @@ def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, i
     h_out = torch.empty_like(h)
     c_out = torch.empty_like(c)
     _lib.call("icap_lstm_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
-              _opt(table, f32, "table"), _opt(ids, i32, "ids"), _chk(h, f32, "h"),
+              _opt(table, f32, "table"), _opt(ids, i32, "ids"), _opt(emb_proj, f32, "emb_proj"),
+              _chk(h, f32, "h"),
               _chk(c, f32, "c"), _chk(kernel, f32, "kernel"),
               _chk(recurrent_kernel, f32, "recurrent_kernel"), _chk(bias, f32, "bias"),
               _chk(h_out, f32, "h_out"), _chk(c_out, f32, "c_out"), N, Cdim, E, H, V,

@@ -99,13 +99,17 @@ int icap_attention_f32(const float* pf, const float* features, const float* q,
  *   x = [ctx[n,:C] | emb_n],  emb_n = table[ids[n]] (ids != NULL) or emb[n] (ids == NULL)
  *   z = x . kernel + h . recurrent_kernel + bias;  i,f,g,o = split(z, 4)
  *   c' = sig(f)*c + sig(i)*tanh(g);  h' = sig(o)*tanh(c')
+ * emb_proj (optional, with ids): [V,4H] = table . kernel[C:C+E] computed once with
+ * icap_dense_f32(table, kernel + C*4H, NULL, emb_proj, V, E, 4H, ...).  The token-only
+ * part of z then is the row emb_proj[ids[n]] and the product runs over [ctx | h] only
+ * (a quarter less work at C = E = H/2); `table` may be NULL in that case.
  * c_out may be the same buffer as c (each element is read and written by one thread);
  * h_out must be a different buffer from h (every workgroup reads all of h).
  * Replaces tf.concat + tf.keras.layers.LSTMCell at
  * decoder/lstm_recurrent_decoder.py:100-102 (and embedding.py:10 when ids != NULL). */
 int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
-                       const int32_t* ids, const float* h, const float* c,
-                       const float* kernel, const float* recurrent_kernel,
+                       const int32_t* ids, const float* emb_proj, const float* h,
+                       const float* c, const float* kernel, const float* recurrent_kernel,
                        const float* bias, float* h_out, float* c_out,
                        int N, int C, int E, int H, int V, icap_stream_t stream);
 
@@ -180,6 +184,10 @@ typedef struct icap_engine icap_engine;
 int icap_engine_create(const icap_config* config, const icap_weights* weights,
                        icap_engine** out);
 int icap_engine_destroy(icap_engine* engine);
+/* Recomputes what the engine derives from the weights (the [V,4H] token part of the LSTM
+ * gates).  icap_engine_create does this once on the null stream and waits for it; call
+ * again after changing the embedding or the LSTM kernel in place. */
+int icap_engine_refresh_weights(icap_engine* engine, icap_stream_t stream);
 /* Bytes of device workspace the engine holds. */
 size_t icap_engine_workspace_bytes(const icap_engine* engine);
 

@@ -148,12 +148,20 @@ def test_lstm_step(ops, N, C, E, H, V, use_ids):
         emb = rng.standard_normal((N, E)).astype(np.float32)
         h1, c1 = ops.lstm_step(to_dev(ctx), to_dev(h), to_dev(c), to_dev(kernel), to_dev(rec),
                                to_dev(bias), emb=to_dev(emb))
+    if use_ids:
+        # same step with the token-only part of the gates pre-multiplied
+        emb_proj = ops.dense(to_dev(table), to_dev(np.ascontiguousarray(kernel[C:])), None)
+        h2, c2 = ops.lstm_step(to_dev(ctx), to_dev(h), to_dev(c), to_dev(kernel), to_dev(rec),
+                               to_dev(bias), ids=to_dev(ids), emb_proj=emb_proj)
     x = np.concatenate([ctx, emb], axis=1)
     h_ref, (_, c_ref) = co.lstm_cell(x.astype(np.float64), h.astype(np.float64),
                                      c.astype(np.float64), kernel.astype(np.float64),
                                      rec.astype(np.float64), bias.astype(np.float64))
     assert_close(np_of(c1), c_ref, what="lstm c")
     assert_close(np_of(h1), h_ref, what="lstm h")
+    if use_ids:
+        assert_close(np_of(c2), c_ref, what="lstm c (emb_proj)")
+        assert_close(np_of(h2), h_ref, what="lstm h (emb_proj)")
 
 
 def test_bad_arguments_raise(ops):
