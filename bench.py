@@ -34,6 +34,22 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32-input MFMA peak of MI355X
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3
+    runs of this same command); None when no profile of this workload is present."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("config") == workload:
+                return d["kernels"]["vocab_projection"]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """The CPU oracle (op-for-op numpy restatement of the reference loop, including the
     un-hoisted W1(features) every step) on a bounded sample of the same workload:
@@ -164,7 +180,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "vocab projection dense_f32 [N,H]x[H,V]",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                         "traffic": measured_traffic(args.config), "avg_launch_us": round(avg_s * 1e6, 2),
                          "launches": n_vocab},
             "hbm_kernels": {"beam_step_GBps": round(beam_gbs, 1), "attention_GBps": round(att_gbs, 1),
                             "peak_GBps": PEAK_HBM_GBS},
