@@ -63,6 +63,11 @@ SIGNATURES = {
                             _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),
     "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
+    "icap_beam_scores_f32": ([_P, _P, _P, _P, _I, _D, _I, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_beam_gather_f32": ([_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "icap_mask_probs_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_hyp_score_f32": ([_P, _P, _D, _P, C.c_longlong, _P], C.c_int),
+    "icap_batch_gather_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_engine_create": ([C.POINTER(IcapConfig), C.POINTER(IcapWeights), C.POINTER(_P)], C.c_int),
     "icap_engine_destroy": ([_P], C.c_int),
     "icap_engine_refresh_weights": ([_P, _P], C.c_int),

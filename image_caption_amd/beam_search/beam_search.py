@@ -3,8 +3,9 @@
 
 State and outputs are torch tensors on the ROCm device with the reference's dtypes:
 log_probs/scores float32, finished bool, lengths / predicted_ids / beam_parent_ids
-int32.  One step is one fused HIP kernel (log-softmax, finished mask, length
-penalty, top-k over W*V, gathers)."""
+int32.  With the default successor choice one step is one fused HIP op (log-softmax,
+finished mask, length penalty, top-k over W*V, gathers); a custom
+`choose_successors_fn` runs between a scores kernel and a gather kernel instead."""
 from __future__ import annotations
 
 from collections import namedtuple
@@ -80,6 +81,35 @@ def choose_top_k(scores_flat, top_k):
     return scores.reshape(shape), ids.reshape(shape)
 
 
+def length_penalty(sequence_lengths, penalty_factor):
+    """(5 + len)^w / 6^w as float32 (reference `:115-128`)."""
+    return ops.hyp_score(None, sequence_lengths.to(torch.int32).contiguous(), penalty_factor)
+
+
+def hyp_score(log_probs, sequence_lengths, length_penalty_weight):
+    """log_probs / length_penalty (reference `:131-141`); the operands broadcast."""
+    lp, ln = torch.broadcast_tensors(log_probs, sequence_lengths)
+    return ops.hyp_score(lp.to(torch.float32).contiguous(), ln.to(torch.int32).contiguous(),
+                         length_penalty_weight)
+
+
+def mask_probs(probs, eos_token, finished):
+    """Finished beams put all probability mass on eos (reference `:165-197`):
+    probs [..., V], finished [...]."""
+    return ops.mask_probs(probs.to(torch.float32).contiguous(), eos_token,
+                          _as_u8(finished).contiguous())
+
+
+def batch_gather(a, b):
+    """Per-row gather a[i, b[i, :]] (reference `:347-358`).  Like the reference, both
+    operands go through float32 and the result is float32."""
+    a32 = a.to(torch.float32).contiguous()
+    idx = b.to(torch.float32).to(torch.int32).contiguous()
+    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= a32.shape[-1]):
+        raise IndexError("batch_gather: index outside [0, %d)" % a32.shape[-1])
+    return ops.batch_gather(a32, idx)
+
+
 def _as_u8(finished):
     return finished.contiguous().view(torch.uint8) if finished.dtype == torch.bool \
         else finished.to(torch.uint8)
@@ -92,9 +122,6 @@ def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None, star
     scored.  `prob_fn` None means log-softmax (the reference default, fused in the
     kernel); a custom callable is applied to the [B*W, V] logits first and its output
     is taken as log-probabilities."""
-    if config.choose_successors_fn not in (None, choose_top_k):
-        raise NotImplementedError(
-            "beam_search_step_batch: only choose_top_k successors are built as a HIP kernel")
     B, Wl, V = logits.shape
     if V != config.vocab_size:
         raise ValueError("logits last dim %d != config.vocab_size %d" % (V, config.vocab_size))
@@ -106,6 +133,9 @@ def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None, star
     if prob_fn is not None:
         logits = prob_fn(logits.reshape(-1, V)).reshape(B, Wl, V).contiguous()
         is_log_prob = True
+    if config.choose_successors_fn not in (None, choose_top_k):
+        return _step_with_custom_successors(time_, logits, beam_state, config, is_log_prob,
+                                            start_offset)
     scores, ids, parents, nlp, nfin, nlen = ops.beam_step(
         logits, beam_state.log_probs.contiguous(), _as_u8(beam_state.finished),
         beam_state.lengths.contiguous(), time_, config.eos_token,
@@ -115,10 +145,43 @@ def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None, star
     return output, next_state
 
 
+def _step_with_custom_successors(time_, logits, beam_state, config, is_log_prob, start_offset):
+    """The unfused step: scores kernel -> caller's choice -> gather kernel.  The callable
+    gets the reference's `scores_flat` ([B, W*V], or [B, V] of beam `start_offset` at time
+    0) and the beam width, and returns (scores [B,K], flat indices [B,K])."""
+    B, Wl, V = logits.shape
+    fin = _as_u8(beam_state.finished).contiguous()
+    lengths = beam_state.lengths.contiguous()
+    scores, totals = ops.beam_scores(logits, beam_state.log_probs.contiguous(), fin, lengths,
+                                     config.eos_token, config.length_penalty_weight,
+                                     input_is_log_prob=is_log_prob)
+    scores_flat = scores.reshape(B, -1) if time_ > 0 else scores[:, start_offset, :]
+    next_scores, word_indices = config.choose_successors_fn(scores_flat, config.beam_width)
+    word_indices = torch.as_tensor(word_indices, device=logits.device).to(torch.int32)
+    word_indices = word_indices.reshape(B, -1).contiguous()
+    if word_indices.numel() and (int(word_indices.min()) < 0 or
+                                 int(word_indices.max()) >= scores_flat.shape[-1]):
+        raise IndexError("choose_successors_fn returned an index outside [0, %d)"
+                         % scores_flat.shape[-1])
+    ids, parents, nlp, nfin, nlen = ops.beam_gather(totals, fin, lengths, word_indices,
+                                                    config.eos_token)
+    next_state = BeamSearchState(log_probs=nlp, lengths=nlen, finished=nfin.view(torch.bool))
+    output = BeamSearchStepOutput(scores=next_scores, predicted_ids=ids, beam_parent_ids=parents)
+    return output, next_state
+
+
 def beam_search_step(time_, logits, beam_state, config):
     """Unbatched step (reference `:200-298`): logits [W, V], state vectors [W]."""
     st = BeamSearchState(beam_state.log_probs.unsqueeze(0), beam_state.finished.unsqueeze(0),
                          beam_state.lengths.unsqueeze(0))
+    fn = config.choose_successors_fn
+    if fn not in (None, choose_top_k):
+        # the caller's function sees the unbatched [W*V] (or [V]) scores of the reference
+        def batched_fn(scores_flat, k, _fn=fn):
+            sc, idx = _fn(scores_flat[0], k)
+            return (torch.as_tensor(sc, device=scores_flat.device).unsqueeze(0),
+                    torch.as_tensor(idx, device=scores_flat.device).unsqueeze(0))
+        config = config._replace(choose_successors_fn=batched_fn)
     out, nst = beam_search_step_batch(time_, logits.unsqueeze(0), st, config)
     return (BeamSearchStepOutput(out.scores[0], out.predicted_ids[0], out.beam_parent_ids[0]),
             BeamSearchState(nst.log_probs[0], nst.finished[0], nst.lengths[0]))

@@ -21,12 +21,12 @@
 // logits streamed twice.
 #include <math.h>
 
+#include "beam_shared.h"
 #include "icap_common.h"
 
 namespace icap {
 namespace {
 
-constexpr int PEN_N = 64;   // host-computed length-penalty table entries (len 0..63)
 constexpr int WL_MAX = 16;  // candidate slots per row in the workspace
 constexpr int EMPTY_IDX = 0x7fffffff;
 
@@ -48,15 +48,8 @@ struct BeamArgs {
   float* ws_score;   // [B*W*WL_MAX]
   float* ws_total;   // [B*W*WL_MAX]
   int* ws_idx;       // [B*W*WL_MAX]
-  float lpw;
-  float pen_den;
-  float pen_table[PEN_N];
+  Penalty pen;
 };
-
-__device__ __forceinline__ float penalty_of(const BeamArgs& p, int len) {
-  if (len >= 0 && len < PEN_N) return p.pen_table[len];
-  return powf(5.0f + (float)len, p.lpw) / p.pen_den;
-}
 
 __device__ __forceinline__ bool cand_better(float sa, int ia, float sb, int ib) {
   // a real candidate always beats an empty slot; otherwise higher score, then lower index
@@ -282,8 +275,8 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
   const float lp = p.log_probs[rw];
   const int len = p.lengths[rw];
   const int flat0 = first ? 0 : w * V;
-  const float pen_eos = penalty_of(p, len);
-  const float pen_oth = penalty_of(p, len + 1);
+  const float pen_eos = penalty_of(p.pen, len);
+  const float pen_oth = penalty_of(p.pen, len + 1);
   // un-normalised total log-prob of logit x, exactly as the reference computes it
   auto total_of = [&](float x) -> float {
     const float pr = p.input_is_log_prob ? x : (x - mx) - lse;
@@ -450,7 +443,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
         else if (j == ncol && p.eos >= ncol && p.eos < V) col = p.eos;
         if (col >= 0) {
           const float total = p.log_probs[rw] + ((col == p.eos) ? 0.f : kF32Min);
-          cs[k] = total / penalty_of(p, p.lengths[rw]);
+          cs[k] = total / penalty_of(p.pen, p.lengths[rw]);
           ct[k] = total;
           ci[k] = flat0 + col;
         }
@@ -617,10 +610,7 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   a.ws_score = reinterpret_cast<float*>(wsp + rows * sizeof(float2));
   a.ws_total = a.ws_score + rows * WL_MAX;
   a.ws_idx = reinterpret_cast<int*>(a.ws_total + rows * WL_MAX);
-  // (5 + len)^w in f32, divided by the double 6^w folded to f32: beam_search.py:127-128
-  a.lpw = (float)length_penalty_weight;
-  a.pen_den = (float)pow(6.0, length_penalty_weight);
-  for (int l = 0; l < PEN_N; ++l) a.pen_table[l] = powf(5.0f + (float)l, a.lpw) / a.pen_den;
+  a.pen = make_penalty(length_penalty_weight);
   const bool vec = (V % 4 == 0) && aligned16(logits);
   if (W <= 1) return dispatch_beam<1>(a, vec, s);
   if (W <= 3) return dispatch_beam<3>(a, vec, s);

@@ -1,0 +1,246 @@
+// Unfused pieces of the beam-search step, for callers that bring their own successor
+// choice (BeamSearchConfig.choose_successors_fn) or call the helper functions directly:
+//
+//   beam_scores_f32    log-softmax + finished mask + running total + length-penalised
+//                      score for every (image, beam, word): materialises the [B,W,V]
+//                      `scores` and `total` tensors of beam_search.py:396-445.
+//   beam_gather_f32    everything after the successor choice (beam_search.py:475-529):
+//                      word / parent split, log-prob gather, finished and length update.
+//   mask_probs_f32, length_penalty_f32, hyp_score_f32, batch_gather_f32
+//                      the stand-alone helpers of beam_search.py:115-141,165-197,347-358.
+//
+// All of it is streaming element-wise work: one 16-byte access per lane where the row
+// layout allows it, two reads of a logit row at most (the second one is L2-hot).
+#include "beam_shared.h"
+#include "icap_common.h"
+
+namespace icap {
+namespace {
+
+constexpr int NT = 256;
+
+struct ScoreArgs {
+  const float* logits;
+  const float* log_probs;
+  const uint8_t* finished;
+  const int32_t* lengths;
+  float* scores;
+  float* totals;
+  int eos, input_is_log_prob, V;
+  Penalty pen;
+};
+
+// One workgroup per (image, beam row).
+template <bool VEC>
+__global__ __launch_bounds__(NT) void beam_scores_kernel(ScoreArgs p) {
+  __shared__ float s_m[NT / 64], s_s[NT / 64];
+  const int V = p.V;
+  const size_t rw = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* row = p.logits + rw * V;
+  float* out_s = p.scores + rw * V;
+  float* out_t = p.totals + rw * V;
+  const bool fin = p.finished[rw] != 0;
+  const float lp = p.log_probs[rw];
+  const int len = p.lengths[rw];
+
+  float mx = 0.f, lse = 0.f;
+  if (!fin && !p.input_is_log_prob) {
+    // streaming (max, sum exp) per thread, then wave and workgroup reductions
+    float m = -INFINITY, sm = 0.f;
+    if (VEC) {
+      for (int c = tid * 4; c < V; c += NT * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + c);
+        const float mn = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        if (mn > -INFINITY)
+          sm = sm * fast_exp(m - mn) + (fast_exp(v.x - mn) + fast_exp(v.y - mn)) +
+               (fast_exp(v.z - mn) + fast_exp(v.w - mn));
+        m = mn;
+      }
+    } else {
+      for (int c = tid; c < V; c += NT) {
+        const float v = row[c];
+        const float mn = fmaxf(m, v);
+        if (mn > -INFINITY) sm = sm * fast_exp(m - mn) + fast_exp(v - mn);
+        m = mn;
+      }
+    }
+    const float mw = wave_max(m);
+    const float sw = wave_sum((m > -INFINITY) ? sm * fast_exp(m - mw) : 0.f);
+    if ((tid & 63) == 0) { s_m[tid >> 6] = mw; s_s[tid >> 6] = sw; }
+    __syncthreads();
+    mx = s_m[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, s_m[i]);
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) tot += (s_m[i] > -INFINITY) ? s_s[i] * fast_exp(s_m[i] - mx) : 0.f;
+    lse = logf(tot);
+  }
+  // A finished beam keeps its length for every word; a live one grows by one except at eos
+  // (beam_search.py:416-437).
+  const float pen_eos = penalty_of(p.pen, len);
+  const float pen_oth = fin ? pen_eos : penalty_of(p.pen, len + 1);
+  auto one = [&](float x, int c, float& t, float& s) {
+    float pr;
+    if (fin) pr = (c == p.eos) ? 0.f : kF32Min;
+    else pr = p.input_is_log_prob ? x : (x - mx) - lse;
+    t = lp + pr;
+    s = t / ((c == p.eos) ? pen_eos : pen_oth);
+  };
+  if (VEC) {
+    for (int c = tid * 4; c < V; c += NT * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c);
+      float4 t, s;
+      one(v.x, c, t.x, s.x);
+      one(v.y, c + 1, t.y, s.y);
+      one(v.z, c + 2, t.z, s.z);
+      one(v.w, c + 3, t.w, s.w);
+      *reinterpret_cast<float4*>(out_t + c) = t;
+      *reinterpret_cast<float4*>(out_s + c) = s;
+    }
+  } else {
+    for (int c = tid; c < V; c += NT) {
+      float t, s;
+      one(row[c], c, t, s);
+      out_t[c] = t;
+      out_s[c] = s;
+    }
+  }
+}
+
+// One thread per chosen successor.
+__global__ __launch_bounds__(NT) void beam_gather_kernel(
+    const float* __restrict__ totals, const uint8_t* __restrict__ finished,
+    const int32_t* __restrict__ lengths, const int32_t* __restrict__ word_indices, int eos,
+    int32_t* __restrict__ ids, int32_t* __restrict__ parents, float* __restrict__ next_lp,
+    uint8_t* __restrict__ next_fin, int32_t* __restrict__ next_len, int B, int W, int V, int K) {
+  const int o = blockIdx.x * NT + threadIdx.x;
+  if (o >= B * K) return;
+  const int b = o / K;
+  long long flat = word_indices[o];
+  const long long hi = (long long)W * V - 1;
+  flat = flat < 0 ? 0 : (flat > hi ? hi : flat);  // host side rejects out-of-range choices
+  const int word = (int)(flat % V);
+  const int parent = (int)(flat / V);
+  const size_t rp = (size_t)b * W + parent;
+  const int pfin = finished[rp] ? 1 : 0;
+  const int nfin = (pfin || word == eos) ? 1 : 0;
+  ids[o] = word;
+  parents[o] = parent;
+  next_lp[o] = totals[(size_t)b * W * V + flat];
+  next_fin[o] = (uint8_t)nfin;
+  next_len[o] = lengths[rp] + ((word != eos && !nfin) ? 1 : 0);
+}
+
+// (1 - fm) * finished_row + fm * probs with fm = 1 - finished, as floats like the reference
+// (a finished row therefore turns an infinite input into NaN exactly as it does there).
+__global__ __launch_bounds__(NT) void mask_probs_kernel(const float* __restrict__ probs,
+                                                        const uint8_t* __restrict__ finished,
+                                                        float* __restrict__ out, int eos,
+                                                        long long total, int V) {
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / V;
+  const int c = (int)(i - r * V);
+  const float fm = 1.0f - (finished[r] ? 1.0f : 0.0f);
+  const float rowv = (c == eos) ? 0.f : kF32Min;
+  out[i] = (1.0f - fm) * rowv + fm * probs[i];
+}
+
+__global__ __launch_bounds__(NT) void hyp_score_kernel(const float* __restrict__ log_probs,
+                                                       const int32_t* __restrict__ lengths,
+                                                       float* __restrict__ out, long long n,
+                                                       Penalty pen) {
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const float pn = penalty_of(pen, lengths[i]);
+  out[i] = log_probs ? log_probs[i] / pn : pn;
+}
+
+__global__ __launch_bounds__(NT) void batch_gather_kernel(const float* __restrict__ a,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int B, int X,
+                                                          int Y) {
+  const int o = blockIdx.x * NT + threadIdx.x;
+  if (o >= B * Y) return;
+  const int b = o / Y;
+  int j = idx[o];
+  j = j < 0 ? 0 : (j >= X ? X - 1 : j);  // host side rejects out-of-range indices
+  out[o] = a[(size_t)b * X + j];
+}
+
+}  // namespace
+
+int beam_scores_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                    const int32_t* lengths, int eos_token, double length_penalty_weight,
+                    int input_is_log_prob, float* scores, float* totals, int B, int W, int V,
+                    hipStream_t s) {
+  ICAP_REQUIRE(logits && log_probs && finished && lengths && scores && totals,
+               "beam_scores_f32: null pointer");
+  ICAP_REQUIRE(B > 0 && W > 0 && V > 0, "beam_scores_f32: bad shape");
+  ICAP_REQUIRE((long long)W * V < (1LL << 31), "beam_scores_f32: W*V overflows int32");
+  ScoreArgs a;
+  a.logits = logits; a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
+  a.scores = scores; a.totals = totals;
+  a.eos = eos_token; a.input_is_log_prob = input_is_log_prob; a.V = V;
+  a.pen = make_penalty(length_penalty_weight);
+  const bool vec = (V % 4 == 0) && aligned16(logits) && aligned16(scores) && aligned16(totals);
+  const dim3 grid((unsigned)((size_t)B * W)), block(NT);
+  if (vec) hipLaunchKernelGGL(beam_scores_kernel<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(beam_scores_kernel<false>, grid, block, 0, s, a);
+  ICAP_LAUNCH_CHECK("beam_scores_kernel");
+  return ICAP_OK;
+}
+
+int beam_gather_f32(const float* totals, const uint8_t* finished, const int32_t* lengths,
+                    const int32_t* word_indices, int eos_token, int32_t* predicted_ids,
+                    int32_t* parent_ids, float* next_log_probs, uint8_t* next_finished,
+                    int32_t* next_lengths, int B, int W, int V, int K, hipStream_t s) {
+  ICAP_REQUIRE(totals && finished && lengths && word_indices, "beam_gather_f32: null input");
+  ICAP_REQUIRE(predicted_ids && parent_ids && next_log_probs && next_finished && next_lengths,
+               "beam_gather_f32: null output");
+  ICAP_REQUIRE(B > 0 && W > 0 && V > 0 && K > 0, "beam_gather_f32: bad shape");
+  ICAP_REQUIRE((long long)W * V < (1LL << 31), "beam_gather_f32: W*V overflows int32");
+  ICAP_REQUIRE((long long)B * K < (1LL << 31), "beam_gather_f32: B*K overflows int32");
+  hipLaunchKernelGGL(beam_gather_kernel, dim3(ceil_div(B * K, NT)), dim3(NT), 0, s, totals,
+                     finished, lengths, word_indices, eos_token, predicted_ids, parent_ids,
+                     next_log_probs, next_finished, next_lengths, B, W, V, K);
+  ICAP_LAUNCH_CHECK("beam_gather_kernel");
+  return ICAP_OK;
+}
+
+int mask_probs_f32(const float* probs, const uint8_t* finished, float* out, int eos_token, int N,
+                   int V, hipStream_t s) {
+  ICAP_REQUIRE(probs && finished && out, "mask_probs_f32: null pointer");
+  ICAP_REQUIRE(N > 0 && V > 0, "mask_probs_f32: bad shape");
+  const long long total = (long long)N * V;
+  ICAP_REQUIRE(total / NT < (1LL << 31), "mask_probs_f32: too many elements");
+  hipLaunchKernelGGL(mask_probs_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s,
+                     probs, finished, out, eos_token, total, V);
+  ICAP_LAUNCH_CHECK("mask_probs_kernel");
+  return ICAP_OK;
+}
+
+int hyp_score_f32(const float* log_probs, const int32_t* lengths, double length_penalty_weight,
+                  float* out, long long n, hipStream_t s) {
+  ICAP_REQUIRE(lengths && out, "hyp_score_f32: null pointer");
+  ICAP_REQUIRE(n > 0 && n / NT < (1LL << 31), "hyp_score_f32: bad element count");
+  hipLaunchKernelGGL(hyp_score_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, s,
+                     log_probs, lengths, out, n, make_penalty(length_penalty_weight));
+  ICAP_LAUNCH_CHECK("hyp_score_kernel");
+  return ICAP_OK;
+}
+
+int batch_gather_f32(const float* a, const int32_t* idx, float* out, int B, int X, int Y,
+                     hipStream_t s) {
+  ICAP_REQUIRE(a && idx && out, "batch_gather_f32: null pointer");
+  ICAP_REQUIRE(B > 0 && X > 0 && Y > 0, "batch_gather_f32: bad shape");
+  ICAP_REQUIRE((long long)B * Y < (1LL << 31), "batch_gather_f32: B*Y overflows int32");
+  hipLaunchKernelGGL(batch_gather_kernel, dim3(ceil_div(B * Y, NT)), dim3(NT), 0, s, a, idx, out,
+                     B, X, Y);
+  ICAP_LAUNCH_CHECK("batch_gather_kernel");
+  return ICAP_OK;
+}
+
+}  // namespace icap

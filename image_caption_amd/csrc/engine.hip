@@ -40,6 +40,13 @@ int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, in
                   double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
                   int, void*, size_t, hipStream_t);
 size_t beam_step_workspace_bytes(int B, int W);
+int beam_scores_f32(const float*, const float*, const uint8_t*, const int32_t*, int, double, int,
+                    float*, float*, int, int, int, hipStream_t);
+int beam_gather_f32(const float*, const uint8_t*, const int32_t*, const int32_t*, int, int32_t*,
+                    int32_t*, float*, uint8_t*, int32_t*, int, int, int, int, hipStream_t);
+int mask_probs_f32(const float*, const uint8_t*, float*, int, int, int, hipStream_t);
+int hyp_score_f32(const float*, const int32_t*, double, float*, long long, hipStream_t);
+int batch_gather_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
 int backtrack(const int32_t*, const int32_t*, const float*, const uint8_t*, int32_t*, int32_t*,
               float*, int, int, int, hipStream_t);
 
@@ -311,6 +318,38 @@ int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_
 }
 
 size_t icap_beam_step_workspace_bytes(int B, int W) { return beam_step_workspace_bytes(B, W); }
+
+int icap_beam_scores_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                         const int32_t* lengths, int eos_token, double length_penalty_weight,
+                         int input_is_log_prob, float* scores, float* totals, int B, int W, int V,
+                         icap_stream_t stream) {
+  return beam_scores_f32(logits, log_probs, finished, lengths, eos_token, length_penalty_weight,
+                         input_is_log_prob, scores, totals, B, W, V, (hipStream_t)stream);
+}
+
+int icap_beam_gather_f32(const float* totals, const uint8_t* finished, const int32_t* lengths,
+                         const int32_t* word_indices, int eos_token, int32_t* predicted_ids,
+                         int32_t* parent_ids, float* next_log_probs, uint8_t* next_finished,
+                         int32_t* next_lengths, int B, int W, int V, int K, icap_stream_t stream) {
+  return beam_gather_f32(totals, finished, lengths, word_indices, eos_token, predicted_ids,
+                         parent_ids, next_log_probs, next_finished, next_lengths, B, W, V, K,
+                         (hipStream_t)stream);
+}
+
+int icap_mask_probs_f32(const float* probs, const uint8_t* finished, float* out, int eos_token,
+                        int N, int V, icap_stream_t stream) {
+  return mask_probs_f32(probs, finished, out, eos_token, N, V, (hipStream_t)stream);
+}
+
+int icap_hyp_score_f32(const float* log_probs, const int32_t* lengths, double length_penalty_weight,
+                       float* out, long long n, icap_stream_t stream) {
+  return hyp_score_f32(log_probs, lengths, length_penalty_weight, out, n, (hipStream_t)stream);
+}
+
+int icap_batch_gather_f32(const float* a, const int32_t* idx, float* out, int B, int X, int Y,
+                          icap_stream_t stream) {
+  return batch_gather_f32(a, idx, out, B, X, Y, (hipStream_t)stream);
+}
 
 int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
                    const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,

@@ -170,3 +170,67 @@ def backtrack(ids, parents, last_scores, last_finished):
               _chk(last_scores, f32, "last_scores"), _chk(last_finished, u8, "last_finished"),
               tokens.data_ptr(), best.data_ptr(), best_s.data_ptr(), T, B, W, current_stream())
     return tokens, best, best_s
+
+
+def beam_scores(logits, log_probs, finished, lengths, eos_token, length_penalty_weight,
+                input_is_log_prob=False):
+    """(scores[B,W,V], totals[B,W,V]) of one beam-search step before the successor choice."""
+    B, W, V = logits.shape
+    scores = torch.empty(B, W, V, dtype=f32, device=logits.device)
+    totals = torch.empty(B, W, V, dtype=f32, device=logits.device)
+    _lib.call("icap_beam_scores_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
+              _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(eos_token),
+              float(length_penalty_weight), 1 if input_is_log_prob else 0, scores.data_ptr(),
+              totals.data_ptr(), B, W, V, current_stream())
+    return scores, totals
+
+
+def beam_gather(totals, finished, lengths, word_indices, eos_token):
+    """The step after the successor choice: word_indices[B,K] (flat into W*V) ->
+    (ids, parents, next_log_probs, next_finished(u8), next_lengths), all [B,K]."""
+    B, W, V = totals.shape
+    K = word_indices.shape[-1]
+    dev = totals.device
+    ids = torch.empty(B, K, dtype=i32, device=dev)
+    parents = torch.empty(B, K, dtype=i32, device=dev)
+    nlp = torch.empty(B, K, dtype=f32, device=dev)
+    nfin = torch.empty(B, K, dtype=u8, device=dev)
+    nlen = torch.empty(B, K, dtype=i32, device=dev)
+    _lib.call("icap_beam_gather_f32", _chk(totals, f32, "totals"), _chk(finished, u8, "finished"),
+              _chk(lengths, i32, "lengths"), _chk(word_indices, i32, "word_indices"),
+              int(eos_token), ids.data_ptr(), parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(),
+              nlen.data_ptr(), B, W, V, K, current_stream())
+    return ids, parents, nlp, nfin, nlen
+
+
+def mask_probs(probs, eos_token, finished):
+    """probs[..., V] with rows of finished beams replaced by the all-mass-on-eos row."""
+    V = probs.shape[-1]
+    N = probs.numel() // V
+    out = torch.empty_like(probs)
+    if N:
+        _lib.call("icap_mask_probs_f32", _chk(probs, f32, "probs"), _chk(finished, u8, "finished"),
+                  out.data_ptr(), int(eos_token), N, V, current_stream())
+    return out
+
+
+def hyp_score(log_probs, lengths, length_penalty_weight):
+    """log_probs / length_penalty(lengths) elementwise (same shapes); log_probs None ->
+    the penalty itself."""
+    out = torch.empty(lengths.shape, dtype=f32, device=lengths.device)
+    if lengths.numel():
+        _lib.call("icap_hyp_score_f32", _opt(log_probs, f32, "log_probs"),
+                  _chk(lengths, i32, "sequence_lengths"), float(length_penalty_weight),
+                  out.data_ptr(), lengths.numel(), current_stream())
+    return out
+
+
+def batch_gather(a, idx):
+    """out[b, y] = a[b, idx[b, y]] (float32 [B,X], int32 [B,Y] -> float32 [B,Y])."""
+    B, X = a.shape
+    Y = idx.shape[-1]
+    out = torch.empty(B, Y, dtype=f32, device=a.device)
+    if B and Y:
+        _lib.call("icap_batch_gather_f32", _chk(a, f32, "a"), _chk(idx, i32, "b"), out.data_ptr(),
+                  B, X, Y, current_stream())
+    return out

@@ -139,6 +139,44 @@ int icap_beam_step_f32(const float* logits, const float* log_probs,
                        int32_t* next_lengths, int B, int W, int V,
                        void* workspace, size_t workspace_bytes, icap_stream_t stream);
 
+/* The beam-search step in two halves, for a caller-supplied successor choice
+ * (BeamSearchConfig.choose_successors_fn other than choose_top_k).
+ * icap_beam_scores_f32 materialises, for every (image, beam, word),
+ *   totals[B,W,V] = log_probs + masked log-softmax(logits)      beam_search.py:396-409
+ *   scores[B,W,V] = totals / length_penalty(lengths')           beam_search.py:416-445
+ * (a live beam grows by one except at eos; a finished beam keeps its length and has
+ * all its mass on eos).  The caller picks K successors per image as flat indices into
+ * [W*V] (at time 0: into the V words of one beam) and icap_beam_gather_f32 does the
+ * rest of the step, beam_search.py:475-529: word = idx mod V, parent = idx div V,
+ * next_log_probs = totals[b, idx], finished / lengths gathered by parent and updated.
+ * Indices must lie in [0, W*V); the kernel clamps, the Python front end raises. */
+int icap_beam_scores_f32(const float* logits, const float* log_probs,
+                         const uint8_t* finished, const int32_t* lengths, int eos_token,
+                         double length_penalty_weight, int input_is_log_prob,
+                         float* scores, float* totals, int B, int W, int V,
+                         icap_stream_t stream);
+int icap_beam_gather_f32(const float* totals, const uint8_t* finished,
+                         const int32_t* lengths, const int32_t* word_indices,
+                         int eos_token, int32_t* predicted_ids, int32_t* parent_ids,
+                         float* next_log_probs, uint8_t* next_finished,
+                         int32_t* next_lengths, int B, int W, int V, int K,
+                         icap_stream_t stream);
+
+/* Stand-alone helpers with the reference's semantics.
+ * icap_mask_probs_f32: rows of finished beams become [f32.min .. 0@eos .. f32.min],
+ *   computed as (1-fm)*row + fm*probs like beam_search/beam_search.py:165-197.
+ * icap_hyp_score_f32: out[i] = log_probs[i] / ((5+len[i])^w / 6^w), beam_search.py:131-141;
+ *   with log_probs == NULL it returns the penalty itself (length_penalty, :115-128).
+ * icap_batch_gather_f32: out[b,y] = a[b, idx[b,y]], beam_search.py:347-358 (the reference
+ *   round-trips through float32; so does this).  Indices must lie in [0, X). */
+int icap_mask_probs_f32(const float* probs, const uint8_t* finished, float* out,
+                        int eos_token, int N, int V, icap_stream_t stream);
+int icap_hyp_score_f32(const float* log_probs, const int32_t* lengths,
+                       double length_penalty_weight, float* out, long long n,
+                       icap_stream_t stream);
+int icap_batch_gather_f32(const float* a, const int32_t* idx, float* out, int B, int X,
+                          int Y, icap_stream_t stream);
+
 /* Back-tracking over T recorded steps: pick the best final beam per image
  * (unfinished beams get -1e9 when any beam of the image is finished, first max
  * wins), then follow parents backwards.  ids/parents are [T,B,W]; tokens is [B,T].

@@ -87,7 +87,8 @@ def test_module_surface_mirrors_the_reference():
                  "create_initial_beam_state", "create_initial_beam_state_batch",
                  "combine_beam_state_batch", "choose_top_k", "beam_search_step",
                  "beam_search_step_batch", "loc_optimal_beam_path", "loc_optimal_beam_path_batch",
-                 "sequence_beam_search"):
+                 "sequence_beam_search", "mask_probs", "hyp_score", "length_penalty",
+                 "batch_gather"):
         assert hasattr(bs, name)
     assert bs.BeamSearchConfig._fields == ("beam_width", "vocab_size", "eos_token",
                                            "length_penalty_weight", "choose_successors_fn")

@@ -195,3 +195,115 @@ def test_choose_top_k_direct(bs):
 def test_empty_sequence_backtrack(bs):
     assert bs.loc_optimal_beam_path_batch([]) == []
     assert bs.loc_optimal_beam_path([]) == []
+
+
+# ---- unfused step: caller-supplied successor choice, and the stand-alone helpers ----
+
+def _even_top_k_np(scores_flat, k):
+    """A deliberately odd successor choice: the best k among even flat indices."""
+    masked = np.where(np.arange(scores_flat.shape[-1]) % 2 == 0, scores_flat, -np.inf)
+    return co.choose_top_k(masked, k)
+
+
+def _even_top_k_torch(scores_flat, k):
+    n = scores_flat.shape[-1]
+    even = (torch.arange(n, device=scores_flat.device) % 2 == 0)
+    masked = torch.where(even, scores_flat, torch.full_like(scores_flat, float("-inf")))
+    v, i = torch.topk(masked, k, dim=-1)
+    return v, i
+
+
+@pytest.mark.parametrize("B,W,V,t,start_offset", [
+    (2, 3, 11, 0, 0), (2, 3, 11, 0, 2), (3, 3, 40, 2, 0), (2, 5, 10000, 3, 0), (2, 4, 4099, 1, 0)])
+def test_custom_successor_fn_step(bs, B, W, V, t, start_offset):
+    rng = np.random.default_rng(100 + B * 7 + W * 3 + V + t)
+    logits = rng.standard_normal((B, W, V)).astype(np.float32) * 2
+    state = _random_state(rng, B, W, t)
+    eos, lpw = 4, 1.0
+    out_o, st_o = co.beam_search_step_batch(
+        t, logits, state, co.BeamSearchConfig(W, V, eos, lpw, _even_top_k_np), start_offset=start_offset)
+    st_g = bs.BeamSearchState(to_dev(state.log_probs), to_dev(state.finished), to_dev(state.lengths))
+    out_g, nst_g = bs.beam_search_step_batch(
+        t, to_dev(logits), st_g, bs.BeamSearchConfig(W, V, eos, lpw, _even_top_k_torch),
+        start_offset=start_offset)
+    np.testing.assert_array_equal(np_of(out_g.predicted_ids), out_o.predicted_ids)
+    np.testing.assert_array_equal(np_of(out_g.beam_parent_ids), out_o.beam_parent_ids)
+    np.testing.assert_array_equal(np_of(nst_g.finished), st_o.finished)
+    np.testing.assert_array_equal(np_of(nst_g.lengths), st_o.lengths)
+    with np.errstate(over="ignore"):
+        assert_close(np.maximum(np_of(out_g.scores), -1e30), np.maximum(out_o.scores, -1e30), what="scores")
+        assert_close(np.maximum(np_of(nst_g.log_probs), -1e30), np.maximum(st_o.log_probs, -1e30),
+                     what="log_probs")
+    assert out_g.predicted_ids.dtype == torch.int32 and nst_g.finished.dtype == torch.bool
+
+
+def test_custom_successor_fn_equals_fused_when_it_is_top_k(bs):
+    rng = np.random.default_rng(5)
+    B, W, V, t = 3, 3, 1000, 2
+    logits = rng.standard_normal((B, W, V)).astype(np.float32)
+    state = _random_state(rng, B, W, t)
+    st_g = bs.BeamSearchState(to_dev(state.log_probs), to_dev(state.finished), to_dev(state.lengths))
+    topk = lambda s, k: torch.topk(s, k, dim=-1)
+    out_a, st_a = bs.beam_search_step_batch(t, to_dev(logits), st_g,
+                                            bs.BeamSearchConfig(W, V, 4, 1.0, topk))
+    out_b, st_b = bs.beam_search_step_batch(t, to_dev(logits), st_g,
+                                            bs.BeamSearchConfig(W, V, 4, 1.0, bs.choose_top_k))
+    np.testing.assert_array_equal(np_of(out_a.predicted_ids), np_of(out_b.predicted_ids))
+    np.testing.assert_array_equal(np_of(out_a.beam_parent_ids), np_of(out_b.beam_parent_ids))
+    np.testing.assert_array_equal(np_of(st_a.lengths), np_of(st_b.lengths))
+    assert_close(np.maximum(np_of(st_a.log_probs), -1e30), np.maximum(np_of(st_b.log_probs), -1e30))
+
+
+def test_custom_successor_fn_unbatched_and_bad_index(bs):
+    rng = np.random.default_rng(6)
+    W, V = 3, 13
+    logits = rng.standard_normal((W, V)).astype(np.float32)
+    st_o = co.BeamSearchState(-np.abs(rng.standard_normal(W)).astype(np.float32),
+                              np.array([False, True, False]), np.array([2, 1, 2], np.int32))
+    out_o, nst_o = co.beam_search_step(1, logits, st_o, co.BeamSearchConfig(W, V, 4, 1.0, _even_top_k_np))
+    seen = {}
+
+    def fn(scores_flat, k):
+        seen["shape"] = tuple(scores_flat.shape)
+        return _even_top_k_torch(scores_flat, k)
+    st_g = bs.BeamSearchState(to_dev(st_o.log_probs), to_dev(st_o.finished), to_dev(st_o.lengths))
+    out_g, nst_g = bs.beam_search_step(1, to_dev(logits), st_g, bs.BeamSearchConfig(W, V, 4, 1.0, fn))
+    assert seen["shape"] == (W * V,)
+    np.testing.assert_array_equal(np_of(out_g.predicted_ids), out_o.predicted_ids)
+    np.testing.assert_array_equal(np_of(out_g.beam_parent_ids), out_o.beam_parent_ids)
+    np.testing.assert_array_equal(np_of(nst_g.lengths), nst_o.lengths)
+    bad = lambda s, k: (s[..., :k], torch.full_like(s[..., :k], W * V).to(torch.int32))
+    with pytest.raises(IndexError):
+        bs.beam_search_step(1, to_dev(logits), st_g, bs.BeamSearchConfig(W, V, 4, 1.0, bad))
+
+
+def test_helper_functions_match_oracle(bs):
+    rng = np.random.default_rng(8)
+    N, V, eos = 6, 37, 4
+    probs = co.log_softmax(rng.standard_normal((N, V)).astype(np.float32))
+    fin = rng.random(N) < 0.5
+    got = np_of(bs.mask_probs(to_dev(probs), eos, to_dev(fin)))
+    np.testing.assert_array_equal(got, co.mask_probs(probs, eos, fin))
+    lens = rng.integers(0, 90, size=(4, 5)).astype(np.int32)     # beyond the 64-entry table too
+    for w in (0.0, 0.7, 1.0, 1.2):
+        assert_close(np_of(bs.length_penalty(to_dev(lens), w)), co.length_penalty(lens, w), rtol=2e-6)
+        lp = -np.abs(rng.standard_normal((4, 5))).astype(np.float32) * 10
+        assert_close(np_of(bs.hyp_score(to_dev(lp), to_dev(lens), w)), co.hyp_score(lp, lens, w),
+                     rtol=2e-6)
+    # small lengths come from a host libm table: bit-exact against numpy there
+    small = np.arange(0, 40, dtype=np.int32)[None]
+    np.testing.assert_array_equal(np_of(bs.length_penalty(to_dev(small), 1.0)),
+                                  co.length_penalty(small, 1.0))
+    lp3 = rng.standard_normal((2, 3, 1)).astype(np.float32)
+    ln3 = rng.integers(0, 9, size=(2, 3, 7)).astype(np.int32)
+    assert_close(np_of(bs.hyp_score(to_dev(lp3), to_dev(ln3), 1.0)), co.hyp_score(lp3, ln3, 1.0),
+                 rtol=2e-6)
+    a = rng.standard_normal((5, 9)).astype(np.float32)
+    idx = rng.integers(0, 9, size=(5, 4)).astype(np.int32)
+    g = bs.batch_gather(to_dev(a), to_dev(idx))
+    assert g.dtype == torch.float32
+    np.testing.assert_array_equal(np_of(g), co.batch_gather(a, idx))
+    ai = rng.integers(0, 50, size=(5, 9)).astype(np.int32)
+    np.testing.assert_array_equal(np_of(bs.batch_gather(to_dev(ai), to_dev(idx))), co.batch_gather(ai, idx))
+    with pytest.raises(IndexError):
+        bs.batch_gather(to_dev(a), to_dev(np.full((5, 1), 9, np.int32)))
