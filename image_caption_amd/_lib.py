@@ -63,6 +63,10 @@ SIGNATURES = {
                             _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),
     "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
+    "icap_packed_weight_bytes": ([_I, _I], C.c_size_t),
+    "icap_pack_weight_bf16": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_dense_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "icap_lstm_step_bf16": ([_P] * 9 + [_I, _I, _I, _I, _P], C.c_int),
     "icap_beam_scores_f32": ([_P, _P, _P, _P, _I, _D, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_beam_gather_f32": ([_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "icap_mask_probs_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
@@ -75,6 +79,7 @@ SIGNATURES = {
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
+    "icap_engine_set_overlap": ([_P, _I], C.c_int),
     "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),
 }
 

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
       float part[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
+        part[r] = 0.f;
+        if (k0 + r >= p.R) continue;  // uniform: the last pass may hold fewer rows
         float a = 0.f;
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch) {
@@ -279,7 +281,17 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
             G, R, stride_g, stride_k, L, U, D, H};
   const bool vec = (U % 4 == 0) && (D % 4 == 0) && aligned16(pf) && aligned16(features) &&
                    aligned16(q) && aligned16(v);
-  const int rb = R >= 4 ? 4 : R;
+  // rows held in registers per pass over PF: the fewest passes, then the fewest idle slots
+  int rb = R;
+  if (R > 5) {
+    int best_passes = 1 << 30, best_waste = 1 << 30;
+    for (int cand = 5; cand >= 3; --cand) {
+      const int passes = ceil_div(R, cand), waste = passes * cand - R;
+      if (passes < best_passes || (passes == best_passes && waste < best_waste)) {
+        best_passes = passes; best_waste = waste; rb = cand;
+      }
+    }
+  }
   const int dpad = ((D + 3) / 4) * 4;
   const size_t smem =
       sizeof(float) * ((size_t)((R * L + 3) / 4) * 4 + ATT_MAX_ROWS + (size_t)ATT_WAVES * rb * dpad);
@@ -288,7 +300,8 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
     case 1: return dispatch_uch<1>(a, vec, smem, s);
     case 2: return dispatch_uch<2>(a, vec, smem, s);
     case 3: return dispatch_uch<3>(a, vec, smem, s);
-    default: return dispatch_uch<4>(a, vec, smem, s);
+    case 4: return dispatch_uch<4>(a, vec, smem, s);
+    default: return dispatch_uch<5>(a, vec, smem, s);
   }
 }
 

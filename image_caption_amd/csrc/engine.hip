@@ -1,6 +1,7 @@
 // C ABI of libicap: argument checking wrappers around the kernels plus the fused
 // whole-sequence decode engine (workspace, step loop, optional per-kernel timing).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -25,11 +26,16 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// kernels (gemm_f32.hip, attention.hip, beam.hip)
+// kernels (gemm_f32.hip, gemm_bf16.hip, attention.hip, beam.hip, beam_unfused.hip)
 int dense_f32(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int lstm_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
                   const float*, const float*, const float*, const float*, const float*, float*,
                   float*, int, int, int, int, int, hipStream_t);
+size_t packed_weight_bytes(int K, int N);
+int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
+int dense_bf16(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
+int lstm_step_bf16(const float*, const float*, const float*, const void*, const float*, const float*,
+                   const int32_t*, float*, float*, int, int, int, int, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, hipStream_t);
@@ -75,9 +81,13 @@ struct icap_engine {
   char* beam_ws;
   size_t beam_ws_bytes;
   float* emb_proj;  // [V,4H] = embedding . lstm_kernel[D:D+E]  (token-only part of the gates)
+  // bf16 mode: weights packed as bf16 [N_pad][K] (null in fp32 mode)
+  enum { PK_ENC, PK_W1, PK_INIT_H, PK_INIT_C, PK_W2, PK_LSTM, PK_LSTM_EMB, PK_FC1, PK_FC2, PK_COUNT };
+  void* pk[PK_COUNT] = {};
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr;
+  bool overlap = true;  // false: everything on the caller's stream (clean per-kernel timing)
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
@@ -110,8 +120,13 @@ int check_config(const icap_config& c) {
   ICAP_REQUIRE(c.tile_mode == ICAP_TILE_REFERENCE || c.tile_mode == ICAP_TILE_REPEAT,
                "engine: unknown tile_mode %d", c.tile_mode);
   ICAP_REQUIRE(c.U % 4 == 0 && c.D % 4 == 0, "engine: U and D must be multiples of 4");
-  if (c.precision != ICAP_PRECISION_FP32)
+  if (c.precision != ICAP_PRECISION_FP32 && c.precision != ICAP_PRECISION_BF16)
     return fail(ICAP_ERR_UNSUPPORTED, "engine: precision %d is not built", c.precision);
+  if (c.precision == ICAP_PRECISION_BF16 &&
+      (c.F % 64 || c.D % 64 || c.E % 64 || c.H % 64))
+    return fail(ICAP_ERR_UNSUPPORTED,
+                "engine: bf16 mode needs F, D, E and H to be multiples of 64 (got %d %d %d %d)", c.F,
+                c.D, c.E, c.H);
   ICAP_REQUIRE((long long)c.B * c.W * (long long)c.V < (1LL << 40), "engine: logits too large");
   return ICAP_OK;
 }
@@ -147,6 +162,14 @@ struct Timed {
     if (rc_ != ICAP_OK) return rc_; \
   } while (0)
 
+// y = act(x . W + b) in the engine's precision; `which` names the packed copy of `wf`.
+int engine_dense(const icap_engine* e, int which, const float* x, const float* wf, const float* bias,
+                 float* y, int M, int K, int N, int act, hipStream_t s) {
+  if (e->cfg.precision == ICAP_PRECISION_BF16)
+    return dense_bf16(x, e->pk[which], bias, y, M, K, N, act, s);
+  return dense_f32(x, wf, bias, y, M, K, N, act, s);
+}
+
 int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_score,
                 hipStream_t s) {
   const icap_config& c = e->cfg;
@@ -156,20 +179,21 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
 
   {  // K0: features = relu(img . Wenc + benc)
     Timed t(e, ICAP_K_ENCODE, s);
-    ICAP_TRY(dense_f32(img, w.enc_kernel, w.enc_bias, e->features, BL, c.F, c.D, ICAP_ACT_RELU, s));
+    ICAP_TRY(engine_dense(e, icap_engine::PK_ENC, img, w.enc_kernel, w.enc_bias, e->features, BL,
+                          c.F, c.D, ICAP_ACT_RELU, s));
   }
   {  // K1: PF = features . W1 + b1   (step invariant, per image)
     Timed t(e, ICAP_K_FEAT_PROJ, s);
-    ICAP_TRY(dense_f32(e->features, w.att_w1_kernel, w.att_w1_bias, e->pf, BL, c.D, c.U,
-                       ICAP_ACT_NONE, s));
+    ICAP_TRY(engine_dense(e, icap_engine::PK_W1, e->features, w.att_w1_kernel, w.att_w1_bias, e->pf,
+                          BL, c.D, c.U, ICAP_ACT_NONE, s));
   }
   {  // K2: h0, c0 per image, expanded to the beam rows
     Timed t(e, ICAP_K_INIT_STATE, s);
     ICAP_TRY(pool_features_f32(e->features, nullptr, e->pooled, c.B, c.L, c.D, s));
-    ICAP_TRY(dense_f32(e->pooled, w.init_h_kernel, w.init_h_bias, e->init_h, c.B, c.D, c.H,
-                       ICAP_ACT_NONE, s));
-    ICAP_TRY(dense_f32(e->pooled, w.init_c_kernel, w.init_c_bias, e->init_c, c.B, c.D, c.H,
-                       ICAP_ACT_NONE, s));
+    ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_H, e->pooled, w.init_h_kernel, w.init_h_bias,
+                          e->init_h, c.B, c.D, c.H, ICAP_ACT_NONE, s));
+    ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_C, e->pooled, w.init_c_kernel, w.init_c_bias,
+                          e->init_c, c.B, c.D, c.H, ICAP_ACT_NONE, s));
     ICAP_TRY(expand_rows_f32(e->init_h, e->h[0], c.B, c.W, c.H, c.reset_state_from_feat,
                              c.tile_mode, s));
     ICAP_TRY(expand_rows_f32(e->init_c, e->c, c.B, c.W, c.H, c.reset_state_from_feat, c.tile_mode,
@@ -193,7 +217,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   auto attention_step = [&](hipStream_t st) -> int {
     {  // K4: q = W2(c) + b2      (the query is the LSTM cell state)
       Timed tm(e, ICAP_K_ATTN_QUERY, st);
-      ICAP_TRY(dense_f32(e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N, c.H, c.U, ICAP_ACT_NONE, st));
+      ICAP_TRY(engine_dense(e, icap_engine::PK_W2, e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N,
+                            c.H, c.U, ICAP_ACT_NONE, st));
     }
     {  // K5: additive attention + beta gate
       Timed tm(e, ICAP_K_ATTENTION, st);
@@ -207,15 +232,19 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   int cur = 0;
   for (int t = 0; t < c.T; ++t) {
     const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
-    if (t > 0) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
+    if (t > 0 && e->overlap) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
     {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
-      ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur], e->c,
-                             w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1],
-                             e->c, N, c.D, c.E, c.H, c.V, s));
+      if (c.precision == ICAP_PRECISION_BF16)
+        ICAP_TRY(lstm_step_bf16(e->ctx, e->h[cur], e->c, e->pk[icap_engine::PK_LSTM], w.lstm_bias,
+                                e->emb_proj, ids, e->h[cur ^ 1], e->c, N, c.D, c.H, c.V, s));
+      else
+        ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur], e->c,
+                               w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1],
+                               e->c, N, c.D, c.E, c.H, c.V, s));
     }
     cur ^= 1;
-    if (t + 1 < c.T) {
+    if (t + 1 < c.T && e->overlap) {
       ICAP_HIP(hipEventRecord(e->ev_lstm, s));
       ICAP_HIP(hipStreamWaitEvent(e->side, e->ev_lstm, 0));
       ICAP_TRY(attention_step(e->side));
@@ -223,12 +252,15 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     }
     {  // K7: fc1
       Timed tm(e, ICAP_K_FC1, s);
-      ICAP_TRY(dense_f32(e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N, c.H, c.H, ICAP_ACT_NONE, s));
+      ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
+                            c.H, c.H, ICAP_ACT_NONE, s));
     }
     {  // K8: vocab projection
       Timed tm(e, ICAP_K_VOCAB, s);
-      ICAP_TRY(dense_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N, c.H, c.V, ICAP_ACT_NONE, s));
+      ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
+                            c.H, c.V, ICAP_ACT_NONE, s));
     }
+    if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s));
     {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
        // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
@@ -255,7 +287,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 101; }
+int icap_version(void) { return 102; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -270,6 +302,25 @@ size_t icap_last_error(char* buf, size_t len) {
 int icap_dense_f32(const float* x, const float* w, const float* bias, float* y, int M, int K,
                    int N, int act, icap_stream_t stream) {
   return dense_f32(x, w, bias, y, M, K, N, act, (hipStream_t)stream);
+}
+
+size_t icap_packed_weight_bytes(int K, int N) { return packed_weight_bytes(K, N); }
+
+int icap_pack_weight_bf16(const float* w, void* packed, int K_src, int N, int k_offset, int K_total,
+                          int gate_units, icap_stream_t stream) {
+  return pack_weight_bf16(w, packed, K_src, N, k_offset, K_total, gate_units, (hipStream_t)stream);
+}
+
+int icap_dense_bf16(const float* x, const void* packed_w, const float* bias, float* y, int M, int K,
+                    int N, int act, icap_stream_t stream) {
+  return dense_bf16(x, packed_w, bias, y, M, K, N, act, (hipStream_t)stream);
+}
+
+int icap_lstm_step_bf16(const float* ctx, const float* h, const float* c, const void* packed_w,
+                        const float* bias, const float* emb_proj, const int32_t* ids, float* h_out,
+                        float* c_out, int N, int C, int H, int V, icap_stream_t stream) {
+  return lstm_step_bf16(ctx, h, c, packed_w, bias, emb_proj, ids, h_out, c_out, N, C, H, V,
+                        (hipStream_t)stream);
 }
 
 int icap_pool_features_f32(const float* features, const float* mask, float* pooled, int G, int L,
@@ -384,6 +435,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
                o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
+  // packed bf16 weights: {K, N} per matrix
+  const int pk_dims[icap_engine::PK_COUNT][2] = {
+      {c.F, c.D}, {c.D, c.U}, {c.D, c.H}, {c.D, c.H}, {c.H, c.U},
+      {c.D + c.H, 4 * c.H}, {c.E, 4 * c.H}, {c.H, c.H}, {c.H, c.V}};
+  size_t o_pk[icap_engine::PK_COUNT] = {};
+  if (c.precision == ICAP_PRECISION_BF16)
+    for (int i = 0; i < icap_engine::PK_COUNT; ++i)
+      o_pk[i] = cv.take<char>(packed_weight_bytes(pk_dims[i][0], pk_dims[i][1]));
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
@@ -391,7 +450,20 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     err = hipMemcpy(&e->att_v_bias, weights->att_v_bias, sizeof(float), hipMemcpyDeviceToHost);
   if (err == hipSuccess)
     err = hipMemcpy(&e->fc3_bias, weights->fc3_bias, sizeof(float), hipMemcpyDeviceToHost);
-  if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+  if (err == hipSuccess) {
+    // The side stream carries work that is off the critical path: give it the lowest
+    // priority so that its workgroups fill the compute units the main stream leaves idle
+    // (small launches, kernel tails) instead of competing with the vocab projection.
+    int prio_low = 0, prio_high = 0;
+    err = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    static const char* prio_env = getenv("ICAP_SIDE_PRIORITY");  // tuning knob: "default"
+    if (err == hipSuccess) {
+      if (prio_env && prio_env[0] == 'd')
+        err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+      else
+        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_low);
+    }
+  }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
   if (err != hipSuccess) {
@@ -415,6 +487,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws = b + o_bws;
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
+  if (c.precision == ICAP_PRECISION_BF16)
+    for (int i = 0; i < icap_engine::PK_COUNT; ++i) e->pk[i] = b + o_pk[i];
   {
     const int rc = icap_engine_refresh_weights(e, nullptr);
     if (rc != ICAP_OK) {
@@ -434,10 +508,28 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
 int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
   ICAP_REQUIRE(e, "icap_engine_refresh_weights: null engine");
   const icap_config& c = e->cfg;
+  const icap_weights& w = e->w;
+  hipStream_t s = (hipStream_t)stream;
+  const float* emb_rows = w.lstm_kernel + (size_t)c.D * 4 * c.H;  // kernel rows of the embedding
+  if (c.precision == ICAP_PRECISION_BF16) {
+    typedef icap_engine E;
+    ICAP_TRY(pack_weight_bf16(w.enc_kernel, e->pk[E::PK_ENC], c.F, c.D, 0, c.F, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.att_w1_kernel, e->pk[E::PK_W1], c.D, c.U, 0, c.D, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.init_h_kernel, e->pk[E::PK_INIT_H], c.D, c.H, 0, c.D, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.init_c_kernel, e->pk[E::PK_INIT_C], c.D, c.H, 0, c.D, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.att_w2_kernel, e->pk[E::PK_W2], c.H, c.U, 0, c.H, 0, s));
+    // gate product over [ctx | h]: kernel rows [0,D) then the recurrent kernel, gates interleaved
+    ICAP_TRY(pack_weight_bf16(w.lstm_kernel, e->pk[E::PK_LSTM], c.D, 4 * c.H, 0, c.D + c.H, c.H, s));
+    ICAP_TRY(pack_weight_bf16(w.lstm_recurrent_kernel, e->pk[E::PK_LSTM], c.H, 4 * c.H, c.D,
+                              c.D + c.H, c.H, s));
+    ICAP_TRY(pack_weight_bf16(emb_rows, e->pk[E::PK_LSTM_EMB], c.E, 4 * c.H, 0, c.E, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.fc1_kernel, e->pk[E::PK_FC1], c.H, c.H, 0, c.H, 0, s));
+    ICAP_TRY(pack_weight_bf16(w.fc2_kernel, e->pk[E::PK_FC2], c.H, c.V, 0, c.H, 0, s));
+  }
   // emb_proj[v] = embedding[v] . lstm_kernel[D:D+E]: the part of the LSTM gates that
   // depends only on the input token, hoisted out of the step loop
-  return dense_f32(e->w.embedding, e->w.lstm_kernel + (size_t)c.D * 4 * c.H, nullptr, e->emb_proj,
-                   c.V, c.E, 4 * c.H, ICAP_ACT_NONE, (hipStream_t)stream);
+  return engine_dense(e, icap_engine::PK_LSTM_EMB, w.embedding, emb_rows, nullptr, e->emb_proj, c.V,
+                      c.E, 4 * c.H, ICAP_ACT_NONE, s);
 }
 
 int icap_engine_destroy(icap_engine* e) {
@@ -479,6 +571,12 @@ int icap_engine_set_timing(icap_engine* e, unsigned class_mask) {
   ICAP_REQUIRE(e, "icap_engine_set_timing: null engine");
   e->timing = class_mask;
   e->spans_used = 0;
+  return ICAP_OK;
+}
+
+int icap_engine_set_overlap(icap_engine* e, int on) {
+  ICAP_REQUIRE(e, "icap_engine_set_overlap: null engine");
+  e->overlap = on != 0;
   return ICAP_OK;
 }
 

@@ -1,0 +1,286 @@
+// bf16-operand contractions for the reduced-precision mode: y = act(x . W + b) and the
+// LSTM gate product with its cell update, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//
+// Activations stay fp32 in memory and are rounded to bf16 (round-to-nearest-even) while
+// they are staged into LDS.  Weights are packed once per engine: transposed to
+// [N_pad][K] bf16 with k contiguous (both MFMA operands then read 8 consecutive k with
+// one ds_read_b128), N padded to a multiple of 128 with zero rows.  The LSTM packing also
+// interleaves the gates in groups of 32 units, so a 128-column tile holds i,f,g,o of the
+// same 32 units and the cell update runs in the epilogue of the same kernel.
+//
+// Tile: BM x 128 x 64 per stage, waves in a 2 x 2 grid, LDS double-buffered, the global
+// loads of stage k+1 in flight during the MFMAs of stage k, one barrier per stage.  LDS
+// rows are 144 bytes (128 of data + 16 pad) so that the 16-byte operand reads of 8
+// consecutive lanes fall in 8 distinct bank groups.
+#include "icap_common.h"
+
+namespace icap {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+constexpr int BN = 128;
+constexpr int ROW_B = BK * 2 + 16;  // bytes per LDS tile row
+constexpr int ZLD = BN + 4;         // floats per row of the gate exchange buffer
+
+struct Bf16Args {
+  const float* a0;  // A = [a0 | a1] along k; a1 may be null (K0 == K)
+  const float* a1;
+  int K0, lda0, lda1;
+  const uint16_t* w;  // packed [N_pad][K]
+  const float* bias;
+  float* y;
+  int M, N, K, act;
+  int tiles_m, tiles_n;
+  // LSTM epilogue
+  const float* c_in;
+  float* h_out;
+  float* c_out;
+  const float* emb_proj;  // [V,4H] token-only gate pre-activations, may be null
+  const int32_t* ids;
+  int H, V;
+};
+
+template <int BM, bool LSTM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
+  constexpr int NT = 256;
+  constexpr int WTM = BM / 2;    // wave tile rows
+  constexpr int TM = WTM / 32;   // accumulators along m
+  constexpr int TN = 2;          // wave tile = WTM x 64
+  constexpr int A_LD = BM * (BK / 4) / NT;  // float4 loads per thread per stage
+  constexpr int B_LD = BN * (BK / 8) / NT;  // 16-byte loads per thread per stage
+  constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int Z_BYTES = LSTM ? BM * ZLD * 4 : 0;
+  constexpr int SMEM = 2 * STAGE > Z_BYTES ? 2 * STAGE : Z_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  int tile_m, tile_n;
+  tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // ---- global -> register staging ----
+  const int a_c4 = tid & 15, a_r = tid >> 4;  // 16 rows per pass
+  const int b_ch = tid & 7, b_r = tid >> 3;   // 32 rows per pass
+  int a_row[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) a_row[i] = min(m0 + a_r + 16 * i, p.M - 1);  // clamped, stores are masked
+  float4 ra[A_LD];
+  uint4 rb[B_LD];
+  // (macros, not lambdas: arrays captured by a lambda are not split into registers)
+#define ICAP_BF16_LOAD(KT)                                                                         \
+  {                                                                                                \
+    const int k0_ = (KT) * BK;                                                                     \
+    const bool seg0_ = k0_ < p.K0; /* uniform over the workgroup */                                \
+    const float* base_ = seg0_ ? p.a0 : p.a1;                                                      \
+    const int ld_ = seg0_ ? p.lda0 : p.lda1;                                                       \
+    const int kk_ = (seg0_ ? k0_ : k0_ - p.K0) + a_c4 * 4;                                         \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                       \
+        *reinterpret_cast<const float4*>(base_ + (size_t)a_row[i] * ld_ + kk_);                    \
+    _Pragma("unroll") for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const uint4*>(      \
+        p.w + (size_t)(n0 + b_r + 32 * j) * p.K + k0_ + b_ch * 8);                                 \
+  }
+#define ICAP_BF16_STORE(BUF)                                                                       \
+  {                                                                                                \
+    char* as_ = smem + (BUF) * STAGE;                                                              \
+    char* bs_ = as_ + A_BYTES;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                             \
+      bf16x4 v_;                                                                                   \
+      v_[0] = (__bf16)ra[i].x; v_[1] = (__bf16)ra[i].y;                                            \
+      v_[2] = (__bf16)ra[i].z; v_[3] = (__bf16)ra[i].w;                                            \
+      *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_c4 * 8) = v_;                    \
+    }                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                               \
+        *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_ch * 16) = rb[j];               \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  ICAP_BF16_LOAD(0)
+  ICAP_BF16_STORE(0)
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    ICAP_BF16_LOAD(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch around loads
+    const char* as = smem + cur * STAGE + (wm * WTM + l31) * ROW_B + half * 16;
+    const char* bs = smem + cur * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * ROW_B + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROW_B + ks * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    ICAP_BF16_STORE(cur ^ 1)
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#undef ICAP_BF16_LOAD
+#undef ICAP_BF16_STORE
+
+  if (!LSTM) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      const bool n_ok = n < p.N;
+      const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] + bv;
+          if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+          if (n_ok && m < p.M) p.y[(size_t)m * p.N + n] = v;
+        }
+    }
+  } else {
+    // gates meet in LDS: column g*32 + u of the tile is gate g of unit n0/4 + u
+    float* zs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          zs[row * ZLD + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        }
+    __syncthreads();
+    const int H = p.H;
+    const int u = tid & 31;
+    const int unit = (n0 >> 2) + u;
+    float bz[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bz[g] = p.bias ? p.bias[g * H + unit] : 0.f;
+    for (int row = tid >> 5; row < BM; row += NT / 32) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = zs[row * ZLD + g * 32 + u] + bz[g];
+      if (p.emb_proj) {
+        int id = p.ids[m];
+        id = min(max(id, 0), p.V - 1);
+        const float* ep = p.emb_proj + (size_t)id * 4 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] += ep[g * H];
+      }
+      const size_t o = (size_t)m * H + unit;
+      const float cn = fast_sigmoid(z[1]) * p.c_in[o] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
+      p.c_out[o] = cn;
+      p.h_out[o] = fast_sigmoid(z[3]) * fast_tanh(cn);
+    }
+  }
+}
+
+// w[K_src][N] fp32 -> packed[n'][k_off + k] bf16, n' = n or the gate-interleaved column.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w,
+                                                          uint16_t* __restrict__ packed, int K_src,
+                                                          int N, int k_off, int K_total,
+                                                          int gate_units) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)K_src * N) return;
+  const int k = (int)(idx / N), n = (int)(idx - (long long)k * N);
+  int np = n;
+  if (gate_units > 0) {
+    const int g = n / gate_units, u = n - g * gate_units;
+    np = (u >> 5) * 128 + g * 32 + (u & 31);
+  }
+  const __bf16 v = (__bf16)w[idx];
+  packed[(size_t)np * K_total + k_off + k] = __builtin_bit_cast(uint16_t, v);
+}
+
+template <int BM, bool LSTM>
+int launch(Bf16Args& a, hipStream_t s, const char* name) {
+  a.tiles_m = ceil_div(a.M, BM);
+  a.tiles_n = ceil_div(a.N, BN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, LSTM>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+  ICAP_LAUNCH_CHECK(name);
+  return ICAP_OK;
+}
+
+}  // namespace
+
+size_t packed_weight_bytes(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  return (size_t)ceil_div(N, BN) * BN * K * sizeof(uint16_t);
+}
+
+int pack_weight_bf16(const float* w, void* packed, int K_src, int N, int k_offset, int K_total,
+                     int gate_units, hipStream_t s) {
+  ICAP_REQUIRE(w && packed, "pack_weight_bf16: null pointer");
+  ICAP_REQUIRE(K_src > 0 && N > 0 && k_offset >= 0 && k_offset + K_src <= K_total,
+               "pack_weight_bf16: rows [%d,%d) outside [0,%d)", k_offset, k_offset + K_src, K_total);
+  ICAP_REQUIRE(aligned16(packed), "pack_weight_bf16: packed buffer must be 16-byte aligned");
+  if (gate_units > 0)
+    ICAP_REQUIRE(N == 4 * gate_units && gate_units % 32 == 0,
+                 "pack_weight_bf16: gate layout needs N == 4*units and units %% 32 == 0");
+  const int n_pad = ceil_div(N, BN) * BN;
+  if (n_pad != N && k_offset == 0)  // zero rows for the padded columns
+    ICAP_HIP(hipMemsetAsync(static_cast<uint16_t*>(packed) + (size_t)N * K_total, 0,
+                            (size_t)(n_pad - N) * K_total * sizeof(uint16_t), s));
+  const long long total = (long long)K_src * N;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
+                     static_cast<uint16_t*>(packed), K_src, N, k_offset, K_total, gate_units);
+  ICAP_LAUNCH_CHECK("pack_weight_kernel");
+  return ICAP_OK;
+}
+
+int dense_bf16(const float* x, const void* packed_w, const float* bias, float* y, int M, int K,
+               int N, int act, hipStream_t s) {
+  ICAP_REQUIRE(x && packed_w && y, "dense_bf16: null pointer");
+  ICAP_REQUIRE(M > 0 && K > 0 && N > 0, "dense_bf16: bad shape M=%d K=%d N=%d", M, K, N);
+  ICAP_REQUIRE(K % BK == 0, "dense_bf16: K=%d must be a multiple of %d", K, BK);
+  ICAP_REQUIRE(aligned16(x) && aligned16(packed_w), "dense_bf16: operands must be 16-byte aligned");
+  ICAP_REQUIRE(act == ICAP_ACT_NONE || act == ICAP_ACT_RELU, "dense_bf16: unknown activation %d", act);
+  Bf16Args a = {};
+  a.a0 = x; a.a1 = nullptr; a.K0 = K; a.lda0 = K; a.lda1 = 0;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = y; a.M = M; a.N = N; a.K = K; a.act = act;
+  // small problems: 64-row tiles keep more compute units busy
+  if ((long long)ceil_div(M, 128) * ceil_div(N, BN) >= 256) return launch<128, false>(a, s, "gemm_bf16_kernel<128>");
+  return launch<64, false>(a, s, "gemm_bf16_kernel<64>");
+}
+
+int lstm_step_bf16(const float* ctx, const float* h, const float* c, const void* packed_w,
+                   const float* bias, const float* emb_proj, const int32_t* ids, float* h_out,
+                   float* c_out, int N, int C, int H, int V, hipStream_t s) {
+  ICAP_REQUIRE(ctx && h && c && packed_w && h_out && c_out, "lstm_step_bf16: null pointer");
+  ICAP_REQUIRE(N > 0 && C > 0 && H > 0, "lstm_step_bf16: bad shape");
+  ICAP_REQUIRE(C % BK == 0 && H % BK == 0, "lstm_step_bf16: C=%d and H=%d must be multiples of %d", C,
+               H, BK);
+  ICAP_REQUIRE((emb_proj == nullptr) == (ids == nullptr),
+               "lstm_step_bf16: emb_proj and ids come together");
+  ICAP_REQUIRE(!emb_proj || V > 0, "lstm_step_bf16: vocabulary size missing");
+  ICAP_REQUIRE(h_out != h, "lstm_step_bf16: h_out must not alias h");
+  ICAP_REQUIRE(aligned16(ctx) && aligned16(h) && aligned16(packed_w),
+               "lstm_step_bf16: operands must be 16-byte aligned");
+  Bf16Args a = {};
+  a.a0 = ctx; a.a1 = h; a.K0 = C; a.lda0 = C; a.lda1 = H;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = nullptr; a.M = N; a.N = 4 * H; a.K = C + H; a.act = ICAP_ACT_NONE;
+  a.c_in = c; a.h_out = h_out; a.c_out = c_out; a.emb_proj = emb_proj; a.ids = ids; a.H = H; a.V = V;
+  return launch<64, true>(a, s, "gemm_bf16_kernel<lstm>");
+}
+
+}  // namespace icap

@@ -14,6 +14,8 @@
 // which k is summed inside a group is therefore permuted, which is irrelevant for
 // the sum being complete.  Result layout of a 32x32 tile: column = l&31,
 // row = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r.
+#include <stdlib.h>
+
 #include "icap_common.h"
 
 namespace icap {
@@ -30,6 +32,7 @@ struct DenseArgs {
   int lda, ldb, ldc;
   int act;
   int tiles_m, tiles_n;
+  int band_order;  // tile order: 0 = down a column of tiles, 1 = across a band of panels
 };
 
 // Guarded 4-float load without control flow: the address is clamped to `safe` (any
@@ -54,20 +57,6 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ row_ptr,
     e[i] = ok ? v : 0.f;
   }
   return make_float4(e[0], e[1], e[2], e[3]);
-}
-
-// XCD-aware tile order.  Workgroups b and b+8 share an XCD (and its L2), so the grid
-// index is first remapped so that every XCD owns one contiguous run of tile numbers
-// (bijective for any tile count), and tile numbers walk down a column of tiles (same
-// B panel, successive M tiles) before moving to the next column.
-__device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n, int& tm,
-                                              int& tn) {
-  const int total = tiles_m * tiles_n;
-  const int q = total >> 3, r = total & 7;
-  const int xcd = pid & 7;
-  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
-  tm = sid % tiles_m;
-  tn = sid / tiles_m;
 }
 
 template <int BM, int BN, int WM, int WN, bool VEC>
@@ -208,7 +197,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
   __shared__ float Bs[2][BK][BN];
 
   int tile_m, tile_n;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  if (p.band_order) tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  else tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -525,6 +515,174 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// LSTM step, wide form: the gate product over [ctx | h] (the token part comes in as
+// emb_proj rows) for shapes whose 96-row x 32-unit patches tile the chip evenly: one
+// workgroup of 12 waves per compute unit (wave = 32 rows x one gate), three waves per
+// SIMD.  Against the 32-row kernel this moves 2.1x fewer operand bytes from L2 per
+// flop (the B tile is shared by three row groups) and halves the barriers (BK = 64,
+// LDS 114 KB, affordable with one workgroup per CU).  Staging is split by role: waves
+// 0-7 fetch the B tile, waves 8-11 the A tile, so every wave issues one uniform run of
+// loads per K step.  Requires C % 64 == 0, H % 64 == 0, 16-byte aligned operands.
+// ---------------------------------------------------------------------------------
+constexpr int LW_BM = 96;
+constexpr int LW_BK = 64;
+constexpr int LW_NT = 768;
+
+__global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))) void lstm_f32_wide_kernel(LstmArgs p) {
+  constexpr int BM = LW_BM, BN = 128, LBK = LW_BK, KQ = LBK / 4;
+  constexpr int A_BYTES = 2 * KQ * (BM + 1) * 16;
+  constexpr int B_BYTES = 2 * LBK * BN * 4;
+  constexpr int Z_BYTES = 4 * BM * 33 * 4;
+  static_assert(Z_BYTES <= A_BYTES + B_BYTES, "gate exchange reuses the staging buffers");
+  constexpr int B_F4 = LBK * BN / 4;                  // float4 per B tile
+  constexpr int B_LD = (B_F4 + LW_NT - 1) / LW_NT;    // per thread per K step (tail clamped)
+  constexpr int A_LD = (BM * KQ) / LW_NT;
+  static_assert(A_LD * LW_NT == BM * KQ, "A tile must divide evenly over the threads");
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + B_BYTES + BM * 4];
+  typedef float4 (*AsT)[KQ][BM + 1];
+  typedef float (*BsT)[LBK][BN];
+  typedef float (*ZsT)[BM][33];
+  AsT As = reinterpret_cast<AsT>(smem);
+  BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
+  ZsT Zs = reinterpret_cast<ZsT>(smem);
+  int* row_src = reinterpret_cast<int*>(smem + A_BYTES + B_BYTES);
+
+  int tile_m, tile_j;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_j, tile_m, tile_j);
+  const int m0 = tile_m * BM;
+  const int j0 = tile_j * 32;
+  const int K = p.C + p.H;
+  const int H4 = 4 * p.H;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int rg = wave >> 2;   // row group: rows 32*rg .. 32*rg+31 of the patch
+  const int gate = wave & 3;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  if (tid < BM) {
+    const int gm = m0 + tid;
+    int src = -1;
+    if (gm < p.N && p.ids) {
+      const int id = p.ids[gm];
+      src = (id >= 0 && id < p.V) ? id : -1;
+    }
+    row_src[tid] = src;
+  }
+  __syncthreads();
+
+  // the token-only part of the pre-activations: issued now, consumed in the epilogue
+  const int j = j0 + l31;
+  const float bz = p.bias[gate * p.H + j];
+  float ep[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int src = row_src[row];
+    const bool ok = p.emb_proj != nullptr && src >= 0;
+    const float v = *(ok ? p.emb_proj + (size_t)src * H4 + gate * p.H + j : p.bias);
+    ep[r] = ok ? v : 0.f;
+  }
+
+  // Staging offsets (elements).  The B tile does not divide evenly over 768 threads: the
+  // surplus threads of the last pass repeat the tile's last vector (same address, same
+  // LDS slot, same value), which keeps the loads free of control flow.
+  int off_b[B_LD], lds_b[B_LD], off_a_ctx[A_LD], off_a_h[A_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int f = min(tid + i * LW_NT, B_F4 - 1);
+    const int c = 4 * (f % (BN / 4));
+    off_b[i] = (f / (BN / 4)) * H4 + (c / 32) * p.H + j0 + (c % 32);
+    lds_b[i] = (f / (BN / 4)) * BN + c;
+  }
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int f = tid + i * LW_NT;
+    const int gm = min(m0 + f / KQ, p.N - 1);  // clamped rows are computed but never stored
+    off_a_ctx[i] = gm * p.C + 4 * (f % KQ);
+    off_a_h[i] = gm * p.H + 4 * (f % KQ);
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  float4 ra[A_LD], rb[B_LD];
+#define ICAP_LW_LOAD(K0)                                                                      \
+  {                                                                                           \
+    const int k0_ = (K0);                                                                     \
+    const bool in_ctx_ = k0_ < p.C; /* uniform: C is a multiple of the K step */              \
+    const float* b_ = in_ctx_ ? p.kernel + (size_t)k0_ * H4                                   \
+                              : p.recurrent + (size_t)(k0_ - p.C) * H4;                       \
+    const float* a_ = in_ctx_ ? p.ctx + k0_ : p.h + (k0_ - p.C);                              \
+    _Pragma("unroll") for (int i = 0; i < B_LD; ++i) rb[i] =                                  \
+        *reinterpret_cast<const float4*>(b_ + off_b[i]);                                      \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                  \
+        *reinterpret_cast<const float4*>(a_ + (in_ctx_ ? off_a_ctx[i] : off_a_h[i]));         \
+  }
+#define ICAP_LW_STORE(BUF)                                                                    \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                          \
+        *reinterpret_cast<float4*>(&Bs[BUF][0][0] + lds_b[i]) = rb[i];                        \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                        \
+      const int f = tid + i * LW_NT;                                                          \
+      As[BUF][f % KQ][f / KQ] = ra[i];                                                        \
+    }                                                                                         \
+  }
+
+  const int nk = K / LBK;
+  ICAP_LW_LOAD(0)
+  ICAP_LW_STORE(0)
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    ICAP_LW_LOAD(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
+#pragma unroll
+    for (int g = 0; g < LBK / 8; ++g) {
+      const float4 a = As[buf][2 * g + half][rg * 32 + l31];
+      float b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = Bs[buf][8 * g + 4 * half + s][gate * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+    }
+    ICAP_LW_STORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef ICAP_LW_LOAD
+#undef ICAP_LW_STORE
+
+  // gate pre-activations to LDS (the staging buffers are idle after the last barrier)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    Zs[gate][row][l31] = (acc[r] + ep[r]) + bz;
+  }
+  __syncthreads();
+  // cell update: 96 x 32 (row, unit) pairs over 768 threads
+  const int u = tid & 31;
+#pragma unroll
+  for (int q = 0; q < BM * 32 / LW_NT; ++q) {
+    const int row = (tid >> 5) + (LW_NT / 32) * q;
+    const int gm = m0 + row;
+    if (gm < p.N) {
+      const float ig = fast_sigmoid(Zs[0][row][u]);
+      const float fg = fast_sigmoid(Zs[1][row][u]);
+      const float gg = fast_tanh(Zs[2][row][u]);
+      const float og = fast_sigmoid(Zs[3][row][u]);
+      const size_t o = (size_t)gm * p.H + j0 + u;
+      const float c_new = fg * p.c[o] + ig * gg;
+      p.c_out[o] = c_new;
+      p.h_out[o] = og * fast_tanh(c_new);
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
   DenseArgs p = a;
@@ -555,7 +713,15 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
                K, N);
   ICAP_REQUIRE(act == ICAP_ACT_NONE || act == ICAP_ACT_RELU, "dense_f32: unknown activation %d",
                act);
-  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0};
+  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0, 0};
+  {
+    // Tile order (tuning knob ICAP_TILE_ORDER=col|band overrides): a band of panels per XCD
+    // when the A operand is too large to stay in one 4 MB L2 next to a B panel.
+    static const char* order_env = getenv("ICAP_TILE_ORDER");
+    const size_t a_bytes = (size_t)M * K * sizeof(float);
+    a.band_order = a_bytes > (size_t)(5 << 19) ? 1 : 0;  // > 2.5 MB
+    if (order_env) a.band_order = order_env[0] == 'b' ? 1 : 0;
+  }
   const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w);
   // 128x128 tiles (8 waves, 32x64 per wave, 2 workgroups = 4 waves per SIMD) when they
   // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
@@ -584,6 +750,24 @@ int lstm_step_f32(const float* ctx, const float* emb, const float* table, const 
   const bool vec = (C % 4 == 0) && (E % 4 == 0) && (H % 4 == 0) && aligned16(ctx) &&
                    (emb_proj || aligned16(ids ? table : emb)) && aligned16(h) &&
                    aligned16(kernel) && aligned16(recurrent);
+  {
+    // wide form when it applies and its 96-row patches use the chip better than 32-row ones
+    static const char* form_env = getenv("ICAP_LSTM_FORM");  // tuning knob: "narrow" | "wide"
+    const bool can_wide = vec && emb_proj && (C % LW_BK == 0) && (H % LW_BK == 0) &&
+                          (long long)N * (C > H ? C : H) < (1LL << 31) &&
+                          (long long)(C + H) * 4 * H < (1LL << 31);
+    const int wide_grid = ceil_div(N, LW_BM) * (H / 32);
+    bool use_wide = can_wide && wide_grid >= 192;
+    if (form_env) use_wide = can_wide && form_env[0] == 'w';
+    if (use_wide) {
+      LstmArgs w = a;
+      w.tiles_m = ceil_div(N, LW_BM);
+      w.tiles_j = H / 32;
+      hipLaunchKernelGGL(lstm_f32_wide_kernel, dim3(wide_grid), dim3(LW_NT), 0, s, w);
+      ICAP_LAUNCH_CHECK("lstm_f32_wide_kernel");
+      return ICAP_OK;
+    }
+  }
   const int grid = a.tiles_m * a.tiles_j;
   if (vec)
     hipLaunchKernelGGL(lstm_f32_kernel<true>, dim3(grid), dim3(256), 0, s, a);

@@ -96,6 +96,39 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f<ICAP_DPP_BCAST31, 0xc>(ninf, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+
+// XCD-aware tile order.  Workgroups b and b+8 share an XCD (and its L2), so the grid
+// index is first remapped so that every XCD owns one contiguous run of tile numbers
+// (bijective for any tile count), and tile numbers walk down a column of tiles (same
+// B panel, successive M tiles) before moving to the next column.
+__device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n, int& tm,
+                                              int& tn) {
+  const int total = tiles_m * tiles_n;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = pid & 7;
+  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+  tm = sid % tiles_m;
+  tn = sid / tiles_m;
+}
+
+// Same XCD remap, but the tile numbers of an XCD sweep a band of ceil(tiles_n/8) column
+// panels with the panel index fastest and the M tile slowest.  The band of B panels stays
+// in the XCD's L2 while every A tile is fetched once per XCD and reused across the band
+// by consecutive workgroups - the order for tall A operands that do not fit in one L2.
+__device__ __forceinline__ void tile_of_block_band(int pid, int tiles_m, int tiles_n, int& tm,
+                                                   int& tn) {
+  const int total = tiles_m * tiles_n;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = pid & 7;
+  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
+  const int pw = (tiles_n + 7) >> 3;        // panels per band
+  const int band_tiles = tiles_m * pw;
+  const int band = sid / band_tiles;
+  const int in_band = sid - band * band_tiles;
+  const int width = min(pw, tiles_n - band * pw);  // the last band may be narrower
+  tm = in_band / width;
+  tn = band * pw + in_band % width;
+}
 #endif
 
 }  // namespace icap

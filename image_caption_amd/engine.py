@@ -150,6 +150,10 @@ class CaptionEngine:
                   out["log_probs"].data_ptr(), ops.current_stream())
         return out
 
+    def set_overlap(self, on):
+        """False keeps every launch on the caller's stream (no side-stream attention)."""
+        _lib.call("icap_engine_set_overlap", self._handle, 1 if on else 0)
+
     def set_timing(self, kernels):
         """kernels: True (all classes), False/None (off) or an iterable of class names
         from _lib.K_NAMES whose launches are bracketed by HIP events."""

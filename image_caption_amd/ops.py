@@ -234,3 +234,56 @@ def batch_gather(a, idx):
         _lib.call("icap_batch_gather_f32", _chk(a, f32, "a"), _chk(idx, i32, "b"), out.data_ptr(),
                   B, X, Y, current_stream())
     return out
+
+
+# ---- bf16-operand mode ---------------------------------------------------------------
+
+class PackedWeight:
+    """A weight matrix packed for the bf16 kernels: bf16, transposed to [N_pad, K]."""
+
+    def __init__(self, K, N, device, gate_units=0):
+        self.K, self.N, self.gate_units = int(K), int(N), int(gate_units)
+        nbytes = int(_lib.load().icap_packed_weight_bytes(self.K, self.N))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def fill(self, kernel, k_offset=0):
+        """Packs rows of `kernel` [K_src, N] at k positions [k_offset, k_offset + K_src)."""
+        K_src, N = kernel.shape
+        if N != self.N:
+            raise ValueError("PackedWeight.fill: kernel has %d columns, expected %d" % (N, self.N))
+        _lib.call("icap_pack_weight_bf16", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
+                  K_src, N, int(k_offset), self.K, self.gate_units, current_stream())
+        return self
+
+
+def pack_weight(kernel, gate_units=0):
+    """kernel [K, N] fp32 -> PackedWeight."""
+    return PackedWeight(kernel.shape[0], kernel.shape[1], kernel.device, gate_units).fill(kernel)
+
+
+def dense_bf16(x, packed, bias=None, act=ACT_NONE):
+    """act(bf16(x) . bf16(W) + bias) with fp32 accumulation; K must be a multiple of 64."""
+    if x.shape[-1] != packed.K:
+        raise ValueError("dense_bf16: input last dim %d != packed K %d" % (x.shape[-1], packed.K))
+    M = x.numel() // packed.K
+    out = torch.empty(*x.shape[:-1], packed.N, dtype=f32, device=x.device)
+    if M:
+        _lib.call("icap_dense_bf16", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+                  out.data_ptr(), M, packed.K, packed.N, act, current_stream())
+    return out
+
+
+def lstm_step_bf16(ctx, h, c, packed, bias, emb_proj=None, ids=None):
+    """One LSTM cell step on [ctx | h] with bf16 operands; `packed` holds kernel[0:C] and the
+    recurrent kernel with interleaved gates (PackedWeight(C + H, 4H, gate_units=H))."""
+    N, C = ctx.shape
+    H = h.shape[-1]
+    if packed.K != C + H or packed.N != 4 * H or packed.gate_units != H:
+        raise ValueError("lstm_step_bf16: packed weight does not match C=%d H=%d" % (C, H))
+    h_out = torch.empty_like(h)
+    c_out = torch.empty_like(c)
+    V = emb_proj.shape[0] if emb_proj is not None else 0
+    _lib.call("icap_lstm_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
+              packed.buf.data_ptr(), _opt(bias, f32, "bias"), _opt(emb_proj, f32, "emb_proj"),
+              _opt(ids, i32, "ids"), h_out.data_ptr(), c_out.data_ptr(), N, C, H, V, current_stream())
+    return h_out, c_out

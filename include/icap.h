@@ -40,7 +40,7 @@ extern "C" {
 #define ICAP_TILE_REPEAT 1    /* row r uses image r / W  (self-consistent layout) */
 
 #define ICAP_PRECISION_FP32 0 /* exact-f32 MFMA everywhere */
-#define ICAP_PRECISION_BF16 1 /* bf16 MFMA for the LSTM-gate and vocab GEMMs, f32 accumulate */
+#define ICAP_PRECISION_BF16 1 /* bf16 operands on MFMA for every dense contraction, f32 accumulate */
 
 #define ICAP_MAX_BEAM_WIDTH 16
 
@@ -112,6 +112,31 @@ int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
                        const float* c, const float* kernel, const float* recurrent_kernel,
                        const float* bias, float* h_out, float* c_out,
                        int N, int C, int E, int H, int V, icap_stream_t stream);
+
+/* ---- bf16-operand mode (ICAP_PRECISION_BF16) -------------------------------------
+ * The dense contractions take bf16 operands (round-to-nearest-even) and accumulate in
+ * fp32; everything else (attention scores, softmax, cell update, beam search) is fp32.
+ * Weights are packed once: bf16, transposed to [N_pad][K_total] with k contiguous and
+ * N_pad = N rounded up to 128.  icap_pack_weight_bf16 writes source rows [0,K_src) of
+ * w[K_src,N] (Keras [in,out] layout) to k positions [k_offset, k_offset+K_src), so a
+ * product over concatenated inputs is packed with one call per source matrix.
+ * gate_units = H > 0 (N == 4H, H % 32 == 0) interleaves the LSTM gates in groups of 32
+ * units as icap_lstm_step_bf16 expects; 0 keeps the column order for icap_dense_bf16.
+ * K must be a multiple of 64.  Same reference call sites as icap_dense_f32 /
+ * icap_lstm_step_f32 (Dense: encoder/mlp_encoder.py:12, attention/attention.py:34-35,
+ * decoder/lstm_recurrent_decoder.py:39-50; LSTMCell: :33-37,102). */
+size_t icap_packed_weight_bytes(int K, int N);
+int icap_pack_weight_bf16(const float* w, void* packed, int K_src, int N, int k_offset,
+                          int K_total, int gate_units, icap_stream_t stream);
+int icap_dense_bf16(const float* x, const void* packed_w, const float* bias, float* y,
+                    int M, int K, int N, int act, icap_stream_t stream);
+/* packed_w: [ctx | h] rows (kernel[0:C] then recurrent_kernel), gates interleaved.
+ * emb_proj/ids: optional token-only gate term (see icap_lstm_step_f32); bias in the
+ * original [4H] order.  c_out may alias c, h_out must not alias h. */
+int icap_lstm_step_bf16(const float* ctx, const float* h, const float* c,
+                        const void* packed_w, const float* bias, const float* emb_proj,
+                        const int32_t* ids, float* h_out, float* c_out,
+                        int N, int C, int H, int V, icap_stream_t stream);
 
 /* Fused beam-search step for B images x W beams x V words: log-softmax, finished
  * masking, accumulated log-prob, length penalty, top-W over the flattened W*V
@@ -260,6 +285,12 @@ int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
 #define ICAP_K_BACKTRACK 9
 #define ICAP_K_COUNT 10
 int icap_engine_set_timing(icap_engine* engine, unsigned class_mask);
+/* By default the attention of step t+1 runs on an engine-owned side stream beside the vocab
+ * projection and beam step of step t (it only depends on the LSTM of step t).  on == 0
+ * keeps every launch on the caller's stream, e.g. to time kernels one by one; results are
+ * identical either way.  No counterpart in the reference (its loop is sequential,
+ * recurrent_example.py:517-558). */
+int icap_engine_set_overlap(icap_engine* engine, int on);
 int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
                              int32_t* launches /*[ICAP_K_COUNT]*/);
 

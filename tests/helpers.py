@@ -37,3 +37,11 @@ def state_to_dev(state):
     from image_caption_amd.beam_search import beam_search as bs
     return bs.BeamSearchState(to_dev(state.log_probs), to_dev(state.finished),
                               to_dev(state.lengths))
+
+
+def round_bf16(x):
+    """float32 array rounded to the nearest bfloat16 (ties to even), returned as float32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(x.shape)

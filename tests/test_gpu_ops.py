@@ -129,7 +129,9 @@ def test_attention(ops, G, R, L, U, D, H, mode, with_bias, with_gate):
 
 @pytest.mark.parametrize("N,C,E,H,V,use_ids", [
     (5, 4, 4, 6, 11, True), (5, 4, 4, 6, 11, False), (7, 6, 5, 9, 13, True),
-    (130, 8, 8, 36, 50, True), (96, 256, 256, 512, 1000, True), (200, 256, 256, 512, 0, False)])
+    (130, 8, 8, 36, 50, True), (96, 256, 256, 512, 1000, True), (200, 256, 256, 512, 0, False),
+    # enough 96-row patches for the one-workgroup-per-CU form of the emb_proj variant:
+    (1152, 64, 64, 512, 300, True), (1100, 128, 64, 512, 300, True), (1536, 256, 256, 512, 10000, True)])
 def test_lstm_step(ops, N, C, E, H, V, use_ids):
     rng = np.random.default_rng(N + C + H)
     kernel = (rng.standard_normal((C + E, 4 * H)) / np.sqrt(C + E)).astype(np.float32)

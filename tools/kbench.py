@@ -64,6 +64,14 @@ def main():
         out = torch.empty(M, Nn, device=dev)
         run(name, lambda: ops.dense(x, w, b, act=act, out=out), flops=2.0 * M * K * Nn)
 
+    # the same contractions with bf16 operands
+    for name, (M, K, Nn, act) in {
+            "bf16 encode": (B * L, F, D, 1), "bf16 fc1": (N, H, H, 0), "bf16 vocab": (N, H, V, 0)}.items():
+        x, w, b = rn(M, K), rn(K, Nn) * 0.05, rn(Nn)
+        pw = ops.pack_weight(w)
+        run(name, lambda: ops.dense_bf16(x, pw, b, act=act), flops=2.0 * M * K * Nn,
+            bytes_=K * Nn * 2.0 + M * K * 4.0 + M * Nn * 4.0)
+
     # lstm
     ctx, h, c = rn(N, D), rn(N, H) * 0.3, rn(N, H) * 0.3
     kern, rec, bias = rn(D + E, 4 * H) * 0.05, rn(H, 4 * H) * 0.05, rn(4 * H) * 0.1
@@ -71,6 +79,13 @@ def main():
     ids = torch.randint(0, V, (N,), dtype=torch.int32, generator=g).to(dev)
     run("lstm_step", lambda: ops.lstm_step(ctx, h, c, kern, rec, bias, table=table, ids=ids),
         flops=2.0 * N * (D + E + H) * 4 * H)
+
+    emb_proj = rn(V, 4 * H) * 0.1
+    run("lstm_step emb_proj", lambda: ops.lstm_step(ctx, h, c, kern, rec, bias, ids=ids, emb_proj=emb_proj),
+        flops=2.0 * N * (D + H) * 4 * H)
+    pk = ops.PackedWeight(D + H, 4 * H, dev, gate_units=H).fill(kern[:D].contiguous(), 0).fill(rec, D)
+    run("bf16 lstm_step", lambda: ops.lstm_step_bf16(ctx, h, c, pk, bias, emb_proj, ids),
+        flops=2.0 * N * (D + H) * 4 * H)
 
     # attention
     pf, feats, q, v = rn(B, L, U), rn(B, L, D).abs(), rn(N, U), rn(U) * 0.1
