@@ -67,6 +67,11 @@ SIGNATURES = {
     "icap_pack_weight_bf16": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_dense_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "icap_lstm_step_bf16": ([_P] * 9 + [_I, _I, _I, _I, _P], C.c_int),
+    "icap_dense_topk_half_tiles": ([_I], C.c_int),
+    "icap_dense_topk_record_floats": ([_I], C.c_int),
+    "icap_dense_topk_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "icap_beam_step_from_records_f32": ([_P, _P, _I, _I, _P, _P, _P, _I, _I, _D, _P, _P, _P, _P,
+                                         _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_beam_scores_f32": ([_P, _P, _P, _P, _I, _D, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_beam_gather_f32": ([_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "icap_mask_probs_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
@@ -80,6 +85,8 @@ SIGNATURES = {
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
     "icap_engine_set_overlap": ([_P, _I], C.c_int),
+    "icap_engine_set_fused_vocab": ([_P, _I], C.c_int),
+    "icap_engine_fused_vocab": ([_P], C.c_int),
     "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),
 }
 

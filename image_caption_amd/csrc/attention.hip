@@ -47,6 +47,7 @@ struct AttArgs {
   float* ctx;      // [N,D]
   float* weights;  // [N,L]
   int G, R, stride_g, stride_k, L, U, D, H;
+  int grid;  // workgroups launched (<= G)
 };
 
 // RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.
@@ -60,11 +61,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   float* s_part = s_beta + ATT_MAX_ROWS;
   const int dpad = ((p.D + 3) / 4) * 4;
 
-  const int g = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
+  float4 v4[UCH];
+#pragma unroll
+  for (int ch = 0; ch < UCH; ++ch) v4[ch] = ld4<VEC>(p.v, ch * 256 + lane * 4, p.U);
+
+  // a workgroup walks groups g, g + gridDim.x, ... (the grid may be capped, see attention_f32)
+  for (int g = blockIdx.x; g < p.G; g += gridDim.x) {
   const float* pf_g = p.pf + (size_t)g * p.L * p.U;
   const float* f_g = p.features + (size_t)g * p.L * p.D;
 
@@ -81,10 +87,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
     }
     if (lane == 0) s_beta[k] = beta;
   }
-
-  float4 v4[UCH];
-#pragma unroll
-  for (int ch = 0; ch < UCH; ++ch) v4[ch] = ld4<VEC>(p.v, ch * 256 + lane * 4, p.U);
 
   // ---- phase 1: scores ----
   for (int k0 = 0; k0 < p.R; k0 += RB) {
@@ -197,16 +199,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
       __syncthreads();
     }
   }
+  }  // groups
 }
 
 template <int RB, int UCH>
 int launch_attention(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
   if (vec)
-    hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, true>), dim3(a.G), dim3(ATT_THREADS), smem,
+    hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, true>), dim3(a.grid), dim3(ATT_THREADS), smem,
                        s, a);
   else
-    hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, false>), dim3(a.G), dim3(ATT_THREADS), smem,
-                       s, a);
+    hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, false>), dim3(a.grid), dim3(ATT_THREADS),
+                       smem, s, a);
   ICAP_LAUNCH_CHECK("attention_f32_kernel");
   return ICAP_OK;
 }
@@ -267,10 +270,14 @@ __global__ __launch_bounds__(256) void embedding_kernel(const float* __restrict_
 
 }  // namespace
 
+// max_workgroups > 0 caps the grid: the workgroups then walk the groups in turn.  A caller
+// that runs this kernel beside a matrix kernel on another stream caps it at one workgroup
+// per compute unit, which leaves the matrix kernel its full occupancy.
 int attention_f32(const float* pf, const float* features, const float* q, const float* v,
                   float bv, const float* score_bias, const float* gate_state,
                   const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
-                  int stride_g, int stride_k, int L, int U, int D, int H, hipStream_t s) {
+                  int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
+                  hipStream_t s) {
   ICAP_REQUIRE(pf && features && q && v && ctx, "attention_f32: null pointer");
   ICAP_REQUIRE(!gate_state || gate_w, "attention_f32: gate_state needs gate_w");
   ICAP_REQUIRE(G > 0 && L > 0 && U > 0 && D > 0, "attention_f32: bad shape");
@@ -278,7 +285,8 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
                ATT_MAX_ROWS);
   ICAP_REQUIRE(!gate_state || H > 0, "attention_f32: H must be positive with a gate");
   AttArgs a{pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
-            G, R, stride_g, stride_k, L, U, D, H};
+            G, R, stride_g, stride_k, L, U, D, H,
+            (max_workgroups > 0 && max_workgroups < G) ? max_workgroups : G};
   const bool vec = (U % 4 == 0) && (D % 4 == 0) && aligned16(pf) && aligned16(features) &&
                    aligned16(q) && aligned16(v);
   // rows held in registers per pass over PF: the fewest passes, then the fewest idle slots

@@ -509,6 +509,222 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
   }
 }
 
+// ---- second half of the fused vocab-projection + beam step ----
+// Input: the per-row records written by the projection's top-k epilogue (for every
+// 64-column half tile of a row: max, sum exp(x - max), the WL largest logits and their
+// columns) and the row's eos logit.  One workgroup per image:
+//   A. one wave per beam row folds the records into the row max and log-sum-exp;
+//   B. every recorded logit becomes a candidate with the exact arithmetic of the reference
+//      ((lp + ((x - max) - lse)) / penalty); finished beams contribute their synthetic
+//      candidates; all of them go to LDS;
+//   C. W rounds of a workgroup-wide argmax (score descending, lower flat index first)
+//      pick the successors; threads 0..W-1 then write the outputs and the next state.
+// A row's best W are always among its half tiles' best WL >= W, so nothing is lost.
+struct RecArgs {
+  const float* rec;    // [B*W][HT][2 + 2*WL]
+  const float* eos_x;  // [B*W]
+  int HT;
+  const float* log_probs;
+  const uint8_t* finished;
+  const int32_t* lengths;
+  int time, eos;
+  float* scores;
+  int32_t* ids;
+  int32_t* parents;
+  float* next_lp;
+  uint8_t* next_fin;
+  int32_t* next_len;
+  int B, W, V;
+  Penalty pen;
+};
+
+template <int WL, int ITEMS>
+__global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
+  constexpr int RL = 2 + 2 * WL;
+  constexpr int NWV = 4;
+  constexpr int MAXW = WL;  // beam width served by this instantiation
+  __shared__ float s_m[NWV][MAXW], s_s[NWV][MAXW];
+  __shared__ float s_bs[NWV], s_bt[NWV];
+  __shared__ int s_bi[NWV];
+  const int W = p.W, V = p.V, HT = p.HT;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool first = p.time <= 0;
+  const int n_rows = first ? 1 : W;  // time 0 scores beam 0 only
+  const int n_rec = n_rows * HT;
+  const size_t row0 = (size_t)b * W;
+
+  // ---- every load of the workgroup is issued here ----
+  // thread t owns records t, t + 256, ... of the image's n_rows * HT (ITEMS of them at most)
+  float4 rr[ITEMS][RL / 4];
+  int rrow[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    const bool ok = idx < n_rec;
+    const int cl = ok ? idx : 0;
+    rrow[it] = ok ? cl / HT : -1;
+    const float4* src = reinterpret_cast<const float4*>(p.rec + (row0 * HT + cl) * RL);
+#pragma unroll
+    for (int q = 0; q < RL / 4; ++q) rr[it][q] = src[q];
+  }
+  // per-row state (n_rows <= MAXW), and this thread's special candidate: thread
+  // w*(W+2)+j makes the j-th synthetic candidate of row w if the row is finished, and the
+  // eos candidate of a live row if j == 0
+  float lp_r[MAXW];
+  int len_r[MAXW];
+  bool fin_r[MAXW];
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    const bool ok = w < n_rows;
+    lp_r[w] = p.log_probs[row0 + (ok ? w : 0)];
+    len_r[w] = p.lengths[row0 + (ok ? w : 0)];
+    fin_r[w] = ok ? p.finished[row0 + w] != 0 : true;
+  }
+  const int sp_w = tid / (W + 2), sp_j = tid - sp_w * (W + 2);
+  const bool sp_on = sp_w < n_rows;
+  const float sp_eos_x = p.eos_x[row0 + (sp_on ? sp_w : 0)];
+
+  // ---- row statistics: (max, sum exp) folded per thread, per wave, then per workgroup ----
+  float Mw[MAXW], Lw[MAXW];
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it)
+      if (rrow[it] == w) m = fmaxf(m, rr[it][0].x);
+    const float mw = wave_max(m);
+    float sm = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it)
+      if (rrow[it] == w && rr[it][0].x > -INFINITY) sm += rr[it][0].y * fast_exp(rr[it][0].x - mw);
+    const float sw = wave_sum(sm);
+    if (lane == 0) { s_m[wave][w] = mw; s_s[wave][w] = sw; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    float M = s_m[0][w];
+#pragma unroll
+    for (int q = 1; q < NWV; ++q) M = fmaxf(M, s_m[q][w]);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) tot += (s_m[q][w] > -INFINITY) ? s_s[q][w] * fast_exp(s_m[q][w] - M) : 0.f;
+    Mw[w] = M;
+    Lw[w] = logf(tot);
+  }
+
+  // ---- this thread's candidates, exact scores ----
+  constexpr int NCAND = ITEMS * WL + 1;
+  float cs[NCAND], ct[NCAND];
+  int ci[NCAND];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int w = rrow[it];
+    float lp = 0.f, M = 0.f, lse = 0.f;
+    int len = 0;
+    bool live = false;
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q)
+      if (q == w) { lp = lp_r[q]; len = len_r[q]; live = !fin_r[q]; M = Mw[q]; lse = Lw[q]; }
+    const float pen_oth = penalty_of(p.pen, len + 1);
+    const int flat0 = first ? 0 : w * V;
+    const float* fl = reinterpret_cast<const float*>(&rr[it][0]);
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const float x = fl[2 + k];
+      const int col = __float_as_int(fl[2 + WL + k]);
+      const float tot = lp + ((x - M) - lse);
+      const float sc = tot / pen_oth;
+      // the eos column is scored by its row's special candidate (its own penalty)
+      const bool ok = live && col >= 0 && col < V && col != p.eos && sc == sc;
+      cs[it * WL + k] = ok ? sc : -INFINITY;
+      ct[it * WL + k] = tot;
+      ci[it * WL + k] = ok ? flat0 + col : EMPTY_IDX;
+    }
+  }
+  {
+    float sc = -INFINITY, tot = 0.f;
+    int fi = EMPTY_IDX;
+    if (sp_on) {
+      float lp = 0.f, M = 0.f, lse = 0.f;
+      int len = 0;
+      bool fin = false;
+#pragma unroll
+      for (int q = 0; q < MAXW; ++q)
+        if (q == sp_w) { lp = lp_r[q]; len = len_r[q]; fin = fin_r[q]; M = Mw[q]; lse = Lw[q]; }
+      const int flat0 = first ? 0 : sp_w * V;
+      const float pen = penalty_of(p.pen, len);
+      if (fin) {
+        // all mass on eos: only the first W+1 columns and the eos column can be selected
+        const int ncol = min(V, W + 1);
+        int col = -1;
+        if (sp_j < ncol) col = sp_j;
+        else if (sp_j == ncol && p.eos >= ncol && p.eos < V) col = p.eos;
+        if (col >= 0) {
+          tot = lp + ((col == p.eos) ? 0.f : kF32Min);
+          sc = tot / pen;
+          fi = flat0 + col;
+        }
+      } else if (sp_j == 0 && p.eos >= 0 && p.eos < V) {
+        tot = lp + ((sp_eos_x - M) - lse);
+        sc = tot / pen;
+        fi = (sc == sc) ? flat0 + p.eos : EMPTY_IDX;
+      }
+    }
+    cs[NCAND - 1] = sc;
+    ct[NCAND - 1] = tot;
+    ci[NCAND - 1] = fi;
+  }
+
+  // ---- W rounds of workgroup-wide argmax; a winner is retired by its owner ----
+  float my_s = -INFINITY, my_t = 0.f;
+  int my_i = EMPTY_IDX;
+  for (int r = 0; r < W; ++r) {
+    float bs = cs[0], bt = ct[0];
+    int bi = ci[0];
+#pragma unroll
+    for (int q = 1; q < NCAND; ++q)
+      if (cand_better(cs[q], ci[q], bs, bi)) { bs = cs[q]; bt = ct[q]; bi = ci[q]; }
+    wave_best(bs, bt, bi);
+    if (lane == 0) { s_bs[wave] = bs; s_bt[wave] = bt; s_bi[wave] = bi; }
+    __syncthreads();
+    bs = s_bs[0]; bt = s_bt[0]; bi = s_bi[0];
+#pragma unroll
+    for (int q = 1; q < NWV; ++q)
+      if (cand_better(s_bs[q], s_bi[q], bs, bi)) { bs = s_bs[q]; bt = s_bt[q]; bi = s_bi[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NCAND; ++q)
+      if (ci[q] == bi && bi != EMPTY_IDX) { cs[q] = -INFINITY; ci[q] = EMPTY_IDX; }
+    if (tid == r) { my_s = bs; my_t = bt; my_i = bi; }
+  }
+
+  // Threads 0..W-1 finish one successor each.  The next-state buffers may be the state
+  // inputs: every thread reads what it needs, then a barrier, then the stores.
+  const bool act = tid < W;
+  const int flat = (my_i == EMPTY_IDX) ? 0 : my_i;
+  const int word = flat % V;
+  const int parent = flat / V;
+  int nfin = 0, nlen = 0;
+  if (act) {
+    const size_t rp = row0 + parent;
+    const int pfin = p.finished[rp] ? 1 : 0;
+    nfin = (pfin || word == p.eos) ? 1 : 0;
+    nlen = p.lengths[rp] + ((word != p.eos && !nfin) ? 1 : 0);
+  }
+  __syncthreads();
+  if (act) {
+    const size_t o = row0 + tid;
+    p.scores[o] = my_s;
+    p.ids[o] = word;
+    p.parents[o] = parent;
+    p.next_lp[o] = my_t;
+    p.next_fin[o] = (uint8_t)nfin;
+    p.next_len[o] = nlen;
+  }
+}
+
 // ---- back-tracking: one thread per image ----
 __global__ __launch_bounds__(256) void backtrack_kernel(const int32_t* __restrict__ ids,
                                                         const int32_t* __restrict__ parents,
@@ -617,6 +833,55 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   if (W <= 5) return dispatch_beam<5>(a, vec, s);
   if (W <= 10) return dispatch_beam<10>(a, vec, s);
   return dispatch_beam<16>(a, vec, s);
+}
+
+// Records one workgroup can hold in registers (8 per thread); more take the unfused kernels.
+bool beam_records_supported(int W, int half_tiles, int top_k) {
+  return W >= 1 && W <= top_k && half_tiles > 0 && (long long)W * half_tiles <= 8 * 256 &&
+         256 >= W * (W + 2);
+}
+
+int beam_step_from_records_f32(const float* records, const float* eos_logit, int half_tiles,
+                               int top_k, const float* log_probs, const uint8_t* finished,
+                               const int32_t* lengths, int time, int eos_token,
+                               double length_penalty_weight, float* scores,
+                               int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                               uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
+                               hipStream_t s) {
+  ICAP_REQUIRE(records && eos_logit && log_probs && finished && lengths,
+               "beam_step_from_records_f32: null input");
+  ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
+                   next_lengths,
+               "beam_step_from_records_f32: null output");
+  ICAP_REQUIRE(B > 0 && V > 0 && half_tiles > 0, "beam_step_from_records_f32: bad shape");
+  ICAP_REQUIRE(top_k == 1 || top_k == 3 || top_k == 5,
+               "beam_step_from_records_f32: top_k must be 1, 3 or 5 (got %d)", top_k);
+  ICAP_REQUIRE(W >= 1 && W <= top_k, "beam_step_from_records_f32: beam width %d exceeds top_k %d",
+               W, top_k);
+  ICAP_REQUIRE(W <= V && (long long)W * V < (1LL << 31), "beam_step_from_records_f32: bad W, V");
+  ICAP_REQUIRE(beam_records_supported(W, half_tiles, top_k),
+               "beam_step_from_records_f32: %d rows x %d records exceed one workgroup", W,
+               half_tiles);
+  RecArgs a;
+  a.rec = records; a.eos_x = eos_logit; a.HT = half_tiles;
+  a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
+  a.time = time; a.eos = eos_token;
+  a.scores = scores; a.ids = predicted_ids; a.parents = parent_ids;
+  a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
+  a.B = B; a.W = W; a.V = V;
+  a.pen = make_penalty(length_penalty_weight);
+  const int items = ceil_div((time <= 0 ? 1 : W) * half_tiles, 256);
+  const dim3 grid(B), block(256);
+#define ICAP_REC_LAUNCH(WL_)                                                                    \
+  if (items <= 2) hipLaunchKernelGGL((beam_records_kernel<WL_, 2>), grid, block, 0, s, a);      \
+  else if (items <= 4) hipLaunchKernelGGL((beam_records_kernel<WL_, 4>), grid, block, 0, s, a); \
+  else hipLaunchKernelGGL((beam_records_kernel<WL_, 8>), grid, block, 0, s, a);
+  if (top_k == 1) { ICAP_REC_LAUNCH(1) }
+  else if (top_k == 3) { ICAP_REC_LAUNCH(3) }
+  else { ICAP_REC_LAUNCH(5) }
+#undef ICAP_REC_LAUNCH
+  ICAP_LAUNCH_CHECK("beam_records_kernel");
+  return ICAP_OK;
 }
 
 int backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,

@@ -36,9 +36,18 @@ int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int dense_bf16(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
 int lstm_step_bf16(const float*, const float*, const float*, const void*, const float*, const float*,
                    const int32_t*, float*, float*, int, int, int, int, hipStream_t);
+int dense_topk_half_tiles(int N);
+int dense_topk_record_floats(int top_k);
+bool dense_topk_supported(const float*, const float*, int, int, int, int);
+int dense_topk_f32(const float*, const float*, const float*, int, int, int, int, int, float*, float*,
+                   hipStream_t);
+bool beam_records_supported(int W, int half_tiles, int top_k);
+int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
+                               const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
+                               uint8_t*, int32_t*, int, int, int, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
-                  int, int, hipStream_t);
+                  int, int, int, hipStream_t);
 int pool_features_f32(const float*, const float*, float*, int, int, int, hipStream_t);
 int expand_rows_f32(const float*, float*, int, int, int, float, int, hipStream_t);
 int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
@@ -84,10 +93,15 @@ struct icap_engine {
   // bf16 mode: weights packed as bf16 [N_pad][K] (null in fp32 mode)
   enum { PK_ENC, PK_W1, PK_INIT_H, PK_INIT_C, PK_W2, PK_LSTM, PK_LSTM_EMB, PK_FC1, PK_FC2, PK_COUNT };
   void* pk[PK_COUNT] = {};
+  // fused vocab projection + beam step: per-row top-k records instead of the [N,V] logits
+  int topk = 0;       // 0: unfused (logits buffer + beam_step kernels)
+  int topk_able = 0;  // the top_k the fused path would use for this shape (0: not served)
+  float *rec = nullptr, *eos_x = nullptr;
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr;
   bool overlap = true;  // false: everything on the caller's stream (clean per-kernel timing)
+  int side_att_wgs = 0;  // grid cap of the attention kernel when it runs on the side stream
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
@@ -224,7 +238,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       Timed tm(e, ICAP_K_ATTENTION, st);
       ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
                              e->c, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
-                             stride_k, c.L, c.U, c.D, c.H, st));
+                             stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st));
     }
     return ICAP_OK;
   };
@@ -255,6 +269,23 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
                             c.H, c.H, ICAP_ACT_NONE, s));
     }
+    const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
+    if (e->topk) {
+      // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
+      {
+        Timed tm(e, ICAP_K_VOCAB, s);
+        ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id, e->topk,
+                                e->rec, e->eos_x, s));
+      }
+      if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s));
+      Timed tm(e, ICAP_K_BEAM, s);
+      ICAP_TRY(beam_step_from_records_f32(
+          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, t, c.eos_id,
+          c.length_penalty_weight, e->hist_scores + (size_t)t * N, e->hist_ids + (size_t)t * N,
+          e->hist_parents + (size_t)t * N, e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W,
+          c.V, s));
+      continue;
+    }
     {  // K8: vocab projection
       Timed tm(e, ICAP_K_VOCAB, s);
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
@@ -264,7 +295,6 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
        // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
-      const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
       ICAP_TRY(beam_step_f32(e->logits, lp_in, e->fin, e->len, t, 0, c.eos_id,
                              c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
                              e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
@@ -287,7 +317,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 102; }
+int icap_version(void) { return 103; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -344,7 +374,7 @@ int icap_attention_f32(const float* pf, const float* features, const float* q, c
                        int rows_per_group, int row_stride_g, int row_stride_k, int L, int U, int D,
                        int H, icap_stream_t stream) {
   return attention_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
-                       G, rows_per_group, row_stride_g, row_stride_k, L, U, D, H,
+                       G, rows_per_group, row_stride_g, row_stride_k, L, U, D, H, 0,
                        (hipStream_t)stream);
 }
 
@@ -402,6 +432,30 @@ int icap_batch_gather_f32(const float* a, const int32_t* idx, float* out, int B,
   return batch_gather_f32(a, idx, out, B, X, Y, (hipStream_t)stream);
 }
 
+int icap_dense_topk_half_tiles(int N) { return dense_topk_half_tiles(N); }
+int icap_dense_topk_record_floats(int top_k) { return dense_topk_record_floats(top_k); }
+
+int icap_dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K, int N,
+                        int eos_token, int top_k, float* records, float* eos_logit,
+                        icap_stream_t stream) {
+  return dense_topk_f32(x, w, bias, M, K, N, eos_token, top_k, records, eos_logit,
+                        (hipStream_t)stream);
+}
+
+int icap_beam_step_from_records_f32(const float* records, const float* eos_logit, int half_tiles,
+                                    int top_k, const float* log_probs, const uint8_t* finished,
+                                    const int32_t* lengths, int time, int eos_token,
+                                    double length_penalty_weight, float* scores,
+                                    int32_t* predicted_ids, int32_t* parent_ids,
+                                    float* next_log_probs, uint8_t* next_finished,
+                                    int32_t* next_lengths, int B, int W, int V,
+                                    icap_stream_t stream) {
+  return beam_step_from_records_f32(records, eos_logit, half_tiles, top_k, log_probs, finished,
+                                    lengths, time, eos_token, length_penalty_weight, scores,
+                                    predicted_ids, parent_ids, next_log_probs, next_finished,
+                                    next_lengths, B, W, V, (hipStream_t)stream);
+}
+
 int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
                    const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,
                    float* best_score, int T, int B, int W, icap_stream_t stream) {
@@ -429,7 +483,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_init_c = cv.take<float>((size_t)c.B * c.H), o_h0 = cv.take<float>(N * c.H),
                o_h1 = cv.take<float>(N * c.H), o_c = cv.take<float>(N * c.H),
                o_q = cv.take<float>(N * c.U), o_ctx = cv.take<float>(N * c.D),
-               o_fc1 = cv.take<float>(N * c.H), o_logits = cv.take<float>(N * c.V),
+               o_fc1 = cv.take<float>(N * c.H), o_logits = cv.take<float>(N * c.V),  // (unused by the fused top-k path)
                o_lp = cv.take<float>(N), o_hs = cv.take<float>(TN), o_hl = cv.take<float>(TN),
                o_len = cv.take<int32_t>(N), o_hi = cv.take<int32_t>(TN),
                o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
@@ -439,6 +493,22 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   const int pk_dims[icap_engine::PK_COUNT][2] = {
       {c.F, c.D}, {c.D, c.U}, {c.D, c.H}, {c.D, c.H}, {c.H, c.U},
       {c.D + c.H, 4 * c.H}, {c.E, 4 * c.H}, {c.H, c.H}, {c.H, c.V}};
+  // Fused vocab projection + beam step when the shape allows it (tuning knob
+  // ICAP_FUSED_TOPK=0 keeps the logits buffer and the separate beam kernels).
+  {
+    static const char* fused_env = getenv("ICAP_FUSED_TOPK");
+    const int tk = c.W <= 1 ? 1 : (c.W <= 3 ? 3 : 5);
+    const bool shape_ok = c.precision == ICAP_PRECISION_FP32 && c.W <= 5 &&
+                          dense_topk_supported(weights->fc2_kernel, weights->fc2_kernel, (int)N, c.H,
+                                               c.V, tk) &&
+                          beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
+    e->topk_able = shape_ok ? tk : 0;
+    e->topk = (fused_env && fused_env[0] == '0') ? 0 : e->topk_able;
+  }
+  const size_t o_rec = cv.take<float>(e->topk_able ? N * dense_topk_half_tiles(c.V) *
+                                                         dense_topk_record_floats(e->topk_able)
+                                                   : 0),
+               o_eosx = cv.take<float>(N);
   size_t o_pk[icap_engine::PK_COUNT] = {};
   if (c.precision == ICAP_PRECISION_BF16)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i)
@@ -464,6 +534,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
         err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_low);
     }
   }
+  if (err == hipSuccess) {
+    // beside the vocab projection the attention kernel gets one workgroup per compute unit
+    // (tuning knob ICAP_SIDE_ATT_WGS: 0 = uncapped)
+    hipDeviceProp_t prop;
+    err = hipGetDeviceProperties(&prop, e->device);
+    static const char* cap_env = getenv("ICAP_SIDE_ATT_WGS");
+    if (err == hipSuccess) e->side_att_wgs = cap_env ? atoi(cap_env) : prop.multiProcessorCount;
+  }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
   if (err != hipSuccess) {
@@ -487,6 +565,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws = b + o_bws;
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
+  e->rec = (float*)(b + o_rec);
+  e->eos_x = (float*)(b + o_eosx);
   if (c.precision == ICAP_PRECISION_BF16)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i) e->pk[i] = b + o_pk[i];
   {
@@ -573,6 +653,18 @@ int icap_engine_set_timing(icap_engine* e, unsigned class_mask) {
   e->spans_used = 0;
   return ICAP_OK;
 }
+
+int icap_engine_set_fused_vocab(icap_engine* e, int on) {
+  ICAP_REQUIRE(e, "icap_engine_set_fused_vocab: null engine");
+  if (on && !e->topk_able)
+    return fail(ICAP_ERR_UNSUPPORTED,
+                "icap_engine_set_fused_vocab: this engine's shape or precision is not served by "
+                "the fused projection (beam width <= 5, fp32, vocab %% 4 == 0, H %% 32 == 0)");
+  e->topk = on ? e->topk_able : 0;
+  return ICAP_OK;
+}
+
+int icap_engine_fused_vocab(const icap_engine* e) { return e && e->topk ? 1 : 0; }
 
 int icap_engine_set_overlap(icap_engine* e, int on) {
   ICAP_REQUIRE(e, "icap_engine_set_overlap: null engine");

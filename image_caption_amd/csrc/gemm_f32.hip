@@ -33,6 +33,10 @@ struct DenseArgs {
   int act;
   int tiles_m, tiles_n;
   int band_order;  // tile order: 0 = down a column of tiles, 1 = across a band of panels
+  // top-k epilogue (dense_topk_f32): per (row, 64-column half tile) records instead of C
+  float* rec;    // [M][2*tiles_n][2 + 2*WL]: max, sum exp(x - max), WL best x, WL columns
+  float* eos_x;  // [M]: the logit of column `eos`
+  int eos;
 };
 
 // Guarded 4-float load without control flow: the address is clamped to `safe` (any
@@ -179,12 +183,46 @@ __global__ __launch_bounds__(WM* WN * 64) void dense_f32_kernel(DenseArgs p) {
   }
 }
 
+
+// Reductions over each 32-lane half of a wavefront (the two halves hold different output
+// rows of a 32x32 MFMA tile); every lane gets the result of its own half.
+__device__ __forceinline__ float half_max(float v, int half) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(1), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(2), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(4), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_ROW_SHR(8), 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<ICAP_DPP_BCAST15, 0xa>(ninf, v));
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return half ? hi : lo;
+}
+__device__ __forceinline__ float half_sum(float v, int half) {
+  v += dpp_f<ICAP_DPP_ROW_SHR(1), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(2), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(4), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_ROW_SHR(8), 0xf>(0.f, v);
+  v += dpp_f<ICAP_DPP_BCAST15, 0xa>(0.f, v);
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return half ? hi : lo;
+}
+
+constexpr int TOPK_EMPTY = 0x7fffffff;
+
 // Fast path of dense_f32: K % 32 == 0, 16-byte aligned operands, element counts below
 // 2^31.  Out-of-range rows / columns of edge tiles are CLAMPED to valid ones instead of
 // masked (their products land in accumulator rows / columns that are never stored), so
 // the K loop has no masks and no per-iteration address arithmetic: every thread keeps
 // 32-bit element offsets and the tile base pointers advance as scalars.
-template <int BM, int BN, int WM, int WN, int MINW>
+//
+// TOPK > 0 replaces the store of C by the fused first half of the beam-search step: every
+// wave reduces its 32 rows x 64 columns to one record per row - the maximum, the sum of
+// exp(x - max) and the TOPK largest values with their columns (ties: lower column) - and
+// the logit of column `eos` is kept aside.  A row's records over all half tiles hold what
+// the log-softmax and the top-k over the whole row need, in 2 + 2*TOPK floats per 64
+// logits, so the [M,N] logits are never written to memory.
+template <int BM, int BN, int WM, int WN, int MINW, int TOPK = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(DenseArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
@@ -193,8 +231,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
   constexpr int B_LD = (BK * BN / 4) / NT;
   constexpr int NG = BK / 8;
 
-  __shared__ float4 As[2][BK / 4][BM + 1];
-  __shared__ float Bs[2][BK][BN];
+  // one LDS object: the A/B staging tiles, aliased (TOPK) by the waves' transposition patches
+  constexpr int T_LD = 68;  // floats per patch row: 16-byte aligned, rows 4 banks apart
+  struct Stage {
+    float4 As[2][BK / 4][BM + 1];
+    float Bs[2][BK][BN];
+  };
+  union Lds {
+    Stage st;
+    float patch[TOPK > 0 ? WM * WN * 32 * T_LD : 1];
+  };
+  __shared__ Lds lds;
+  auto& As = lds.st.As;
+  auto& Bs = lds.st.Bs;
 
   int tile_m, tile_n;
   if (p.band_order) tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
@@ -293,22 +342,129 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
     __syncthreads();
   }
 
+  if constexpr (TOPK == 0) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + l31;
-    if (col >= p.N) continue;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < p.M) {
-          float v = acc[i][j][r] + bv;
-          if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
-          p.C[(size_t)row * p.ldc + col] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+            p.C[(size_t)row * p.ldc + col] = v;
+          }
         }
       }
+    }
+  } else {
+    static_assert(TOPK == 0 || (TM == 1 && TN == 2), "the top-k epilogue assumes 32x64 wave tiles");
+    constexpr int RL = 2 + 2 * TOPK;
+    const int ht = 2 * tile_n + wn;       // half-tile index of this wave within the row
+    const int n_ht = 2 * p.tiles_n;
+    const int colbase = n0 + wn * 64;     // first column of the wave's patch
+    // 1. the wave's 32 x 64 patch (+ bias, -inf beyond N) goes to LDS, row-major, so that
+    //    the reductions over a row become lane-local (the staging tiles are idle: the K
+    //    loop ended on a barrier)
+    float* patch = lds.patch + wave * 32 * T_LD;
+    {
+      const int col0 = colbase + l31, col1 = col0 + 32;
+      const bool ok0 = col0 < p.N, ok1 = col1 < p.N;
+      const float bv0 = (p.bias && ok0) ? p.bias[col0] : 0.f;
+      const float bv1 = (p.bias && ok1) ? p.bias[col1] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;
+        patch[lr * T_LD + l31] = ok0 ? acc[0][0][r] + bv0 : -INFINITY;
+        patch[lr * T_LD + 32 + l31] = ok1 ? acc[0][1][r] + bv1 : -INFINITY;
+      }
+    }
+    __syncthreads();
+    // 2. lane (row = lane/2, part = lane%2) scans 32 consecutive columns of its row
+    const int lr = lane >> 1, part = lane & 1;
+    const int row = m0 + wm * 32 + lr;
+    const int cbase = colbase + part * 32;
+    float x[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(patch + lr * T_LD + part * 32 + 4 * q);
+      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    float tx[TOPK];
+    int tc[TOPK];
+#pragma unroll
+    for (int k = 0; k < TOPK; ++k) { tx[k] = -INFINITY; tc[k] = TOPK_EMPTY; }
+    float eos_v = 0.f;
+    bool has_eos = false;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float v = x[e];
+      const int c = cbase + e;
+      if (c == p.eos) { eos_v = v; has_eos = true; }
+      // insert (v, c) into the descending list; strict '>' keeps the lower column on ties
+      bool gt[TOPK];
+#pragma unroll
+      for (int k = 0; k < TOPK; ++k) gt[k] = v > tx[k];
+#pragma unroll
+      for (int k = TOPK - 1; k >= 1; --k) {
+        tx[k] = gt[k - 1] ? tx[k - 1] : (gt[k] ? v : tx[k]);
+        tc[k] = gt[k - 1] ? tc[k - 1] : (gt[k] ? c : tc[k]);
+      }
+      tx[0] = gt[0] ? v : tx[0];
+      tc[0] = gt[0] ? c : tc[0];
+    }
+    float m = tx[0];
+    const float ms = (m > -INFINITY) ? m : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; e += 4)
+      sum += (fast_exp(x[e] - ms) + fast_exp(x[e + 1] - ms)) + (fast_exp(x[e + 2] - ms) + fast_exp(x[e + 3] - ms));
+    // 3. the two lanes of a row meet (neighbour swap inside each quad)
+    constexpr int SWAP = 0xB1;  // quad_perm [1,0,3,2]
+    const float om = dpp_f<SWAP, 0xf>(0.f, m);
+    const float osum = dpp_f<SWAP, 0xf>(0.f, sum);
+    float ox[TOPK];
+    int oc[TOPK];
+#pragma unroll
+    for (int k = 0; k < TOPK; ++k) {
+      ox[k] = dpp_f<SWAP, 0xf>(0.f, tx[k]);
+      oc[k] = dpp_i<SWAP, 0xf>(0, tc[k]);
+    }
+    if (has_eos && row < p.M) p.eos_x[row] = eos_v;
+    if (part == 0 && row < p.M) {
+      // this lane's columns are the lower ones: on equal values its entries come first
+      const float M2 = fmaxf(m, om);
+      const float M2s = (M2 > -INFINITY) ? M2 : 0.f;
+      const float S2 = ((m > -INFINITY) ? sum * fast_exp(m - M2s) : 0.f) +
+                       ((om > -INFINITY) ? osum * fast_exp(om - M2s) : 0.f);
+      float out[RL];
+      out[0] = M2;
+      out[1] = S2;
+      // merge two descending lists (static indices only: each output picks by counting)
+      int ia = 0, ib = 0;
+#pragma unroll
+      for (int k = 0; k < TOPK; ++k) {
+        float av = -INFINITY, bvv = -INFINITY;
+        int ac = TOPK_EMPTY, bc = TOPK_EMPTY;
+#pragma unroll
+        for (int q = 0; q < TOPK; ++q) {
+          if (q == ia) { av = tx[q]; ac = tc[q]; }
+          if (q == ib) { bvv = ox[q]; bc = oc[q]; }
+        }
+        const bool take_a = (ac != TOPK_EMPTY) && (bc == TOPK_EMPTY || av >= bvv);
+        out[2 + k] = take_a ? av : bvv;
+        out[2 + TOPK + k] = __int_as_float(take_a ? ac : bc);
+        ia += take_a ? 1 : 0;
+        ib += take_a ? 0 : 1;
+      }
+      float4* dst = reinterpret_cast<float4*>(p.rec + ((size_t)row * n_ht + ht) * RL);
+#pragma unroll
+      for (int q = 0; q < RL / 4; ++q)
+        dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
     }
   }
 }
@@ -713,7 +869,7 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
                K, N);
   ICAP_REQUIRE(act == ICAP_ACT_NONE || act == ICAP_ACT_RELU, "dense_f32: unknown activation %d",
                act);
-  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0, 0};
+  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0, 0, nullptr, nullptr, -1};
   {
     // Tile order (tuning knob ICAP_TILE_ORDER=col|band overrides): a band of panels per XCD
     // when the A operand is too large to stay in one 4 MB L2 next to a B panel.
@@ -728,6 +884,38 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
   if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 3>(a, vec, s);
   return launch_dense<64, 64, 2, 2, 2>(a, vec, s);
+}
+
+// Records per row and floats per record of dense_topk_f32 (0 when the shape is not served).
+int dense_topk_half_tiles(int N) { return N > 0 ? 2 * ceil_div(N, 128) : 0; }
+int dense_topk_record_floats(int top_k) { return (top_k == 1 || top_k == 3 || top_k == 5) ? 2 + 2 * top_k : 0; }
+
+bool dense_topk_supported(const float* x, const float* w, int M, int K, int N, int top_k) {
+  return dense_topk_record_floats(top_k) != 0 && M > 0 && K > 0 && N > 0 && (K % BK == 0) &&
+         (N % 4 == 0) && N >= 4 && aligned16(x) && aligned16(w) &&
+         (long long)M * K < (1LL << 31) && (long long)K * N < (1LL << 31);
+}
+
+int dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K, int N,
+                   int eos, int top_k, float* records, float* eos_logit, hipStream_t s) {
+  ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_f32: null pointer");
+  ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k),
+               "dense_topk_f32: needs top_k in {1,3,5}, K %% 32 == 0, N %% 4 == 0 and 16-byte "
+               "aligned operands (M=%d K=%d N=%d top_k=%d)", M, K, N, top_k);
+  ICAP_REQUIRE(aligned16(records), "dense_topk_f32: records must be 16-byte aligned");
+  DenseArgs a{x, w, bias, nullptr, M, N, K, K, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, 128);
+  a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  if (top_k == 1)
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 1>), grid, block, 0, s, a);
+  else if (top_k == 3)
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 3>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 5>), grid, block, 0, s, a);
+  ICAP_LAUNCH_CHECK("dense_f32_fast_kernel<topk>");
+  return ICAP_OK;
 }
 
 int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,

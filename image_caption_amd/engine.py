@@ -150,6 +150,15 @@ class CaptionEngine:
                   out["log_probs"].data_ptr(), ops.current_stream())
         return out
 
+    @property
+    def fused_vocab(self):
+        """True when the vocab projection and the beam step run fused (no logits buffer)."""
+        return bool(_lib.load().icap_engine_fused_vocab(self._handle))
+
+    def set_fused_vocab(self, on):
+        """Select the fused (default where served) or the unfused projection + beam step."""
+        _lib.call("icap_engine_set_fused_vocab", self._handle, 1 if on else 0)
+
     def set_overlap(self, on):
         """False keeps every launch on the caller's stream (no side-stream attention)."""
         _lib.call("icap_engine_set_overlap", self._handle, 1 if on else 0)

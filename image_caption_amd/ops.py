@@ -287,3 +287,46 @@ def lstm_step_bf16(ctx, h, c, packed, bias, emb_proj=None, ids=None):
               packed.buf.data_ptr(), _opt(bias, f32, "bias"), _opt(emb_proj, f32, "emb_proj"),
               _opt(ids, i32, "ids"), h_out.data_ptr(), c_out.data_ptr(), N, C, H, V, current_stream())
     return h_out, c_out
+
+
+# ---- fused vocab projection + beam step ----------------------------------------------
+
+def dense_topk(x, kernel, bias, eos_token, top_k):
+    """Logits x . kernel + bias reduced on the fly to per-row records (see icap.h):
+    returns (records [M, half_tiles, 2 + 2*top_k] float32, eos_logit [M] float32)."""
+    K, N = kernel.shape
+    M = x.numel() // K
+    lib = _lib.load()
+    ht, rl = int(lib.icap_dense_topk_half_tiles(N)), int(lib.icap_dense_topk_record_floats(top_k))
+    if rl == 0:
+        raise ValueError("dense_topk: top_k must be 1, 3 or 5")
+    rec = torch.empty(M, ht, rl, dtype=f32, device=x.device)
+    eos_logit = torch.zeros(M, dtype=f32, device=x.device)
+    _lib.call("icap_dense_topk_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
+              _opt(bias, f32, "bias"), M, K, N, int(eos_token), int(top_k), rec.data_ptr(),
+              eos_logit.data_ptr(), current_stream())
+    return rec, eos_logit
+
+
+def beam_step_from_records(rec, eos_logit, log_probs, finished, lengths, time, eos_token,
+                           length_penalty_weight, V):
+    """beam_step on the records of dense_topk; state tensors [B, W]."""
+    B, W = log_probs.shape
+    M, ht, rl = rec.shape
+    if M != B * W:
+        raise ValueError("beam_step_from_records: %d record rows for B*W = %d" % (M, B * W))
+    top_k = (rl - 2) // 2
+    dev = rec.device
+    scores = torch.empty(B, W, dtype=f32, device=dev)
+    ids = torch.empty(B, W, dtype=i32, device=dev)
+    parents = torch.empty(B, W, dtype=i32, device=dev)
+    nlp = torch.empty(B, W, dtype=f32, device=dev)
+    nfin = torch.empty(B, W, dtype=u8, device=dev)
+    nlen = torch.empty(B, W, dtype=i32, device=dev)
+    _lib.call("icap_beam_step_from_records_f32", _chk(rec, f32, "records"),
+              _chk(eos_logit, f32, "eos_logit"), ht, top_k, _chk(log_probs, f32, "log_probs"),
+              _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(time),
+              int(eos_token), float(length_penalty_weight), scores.data_ptr(), ids.data_ptr(),
+              parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(), B, W, int(V),
+              current_stream())
+    return scores, ids, parents, nlp, nfin, nlen

@@ -202,6 +202,34 @@ int icap_hyp_score_f32(const float* log_probs, const int32_t* lengths,
 int icap_batch_gather_f32(const float* a, const int32_t* idx, float* out, int B, int X,
                           int Y, icap_stream_t stream);
 
+/* Fused form of the vocab projection and the beam step, used by the engine when the
+ * beam width is at most 5: the [M,N] logits are never written to memory.
+ * icap_dense_topk_f32 computes x[M,K] . w[K,N] + bias like icap_dense_f32 (same kernel,
+ * same sums) but its epilogue keeps, for every row and every 64-column half tile, one
+ * record of icap_dense_topk_record_floats(top_k) = 2 + 2*top_k floats:
+ *   [max, sum exp(x - max), the top_k largest logits, their columns (int32 bits,
+ *    0x7fffffff = none; equal logits: lower column first)]
+ * records is [M][icap_dense_topk_half_tiles(N)][2 + 2*top_k], 16-byte aligned;
+ * eos_logit[M] receives the logit of column eos_token (untouched if it is outside [0,N)).
+ * Needs top_k in {1,3,5}, K % 32 == 0, N % 4 == 0, 16-byte aligned x and w.
+ * icap_beam_step_from_records_f32 is icap_beam_step_f32 (start_offset 0, log-softmax
+ * input) reading those records (M = B*W rows, W <= top_k).  The two together replace fc2
+ * at decoder/lstm_recurrent_decoder.py:112 and beam_search_step_batch,
+ * beam_search/beam_search.py:360-543. */
+int icap_dense_topk_half_tiles(int N);
+int icap_dense_topk_record_floats(int top_k);
+int icap_dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K,
+                        int N, int eos_token, int top_k, float* records, float* eos_logit,
+                        icap_stream_t stream);
+int icap_beam_step_from_records_f32(const float* records, const float* eos_logit,
+                                    int half_tiles, int top_k, const float* log_probs,
+                                    const uint8_t* finished, const int32_t* lengths,
+                                    int time, int eos_token, double length_penalty_weight,
+                                    float* scores, int32_t* predicted_ids,
+                                    int32_t* parent_ids, float* next_log_probs,
+                                    uint8_t* next_finished, int32_t* next_lengths,
+                                    int B, int W, int V, icap_stream_t stream);
+
 /* Back-tracking over T recorded steps: pick the best final beam per image
  * (unfinished beams get -1e9 when any beam of the image is finished, first max
  * wins), then follow parents backwards.  ids/parents are [T,B,W]; tokens is [B,T].
@@ -291,6 +319,14 @@ int icap_engine_set_timing(icap_engine* engine, unsigned class_mask);
  * identical either way.  No counterpart in the reference (its loop is sequential,
  * recurrent_example.py:517-558). */
 int icap_engine_set_overlap(icap_engine* engine, int on);
+/* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
+ * icap_beam_step_from_records_f32) whenever its shape is served: fp32, beam width <= 5,
+ * V % 4 == 0, H % 32 == 0.  on == 0 selects the unfused kernels (a [B*W,V] logits buffer,
+ * icap_dense_f32 + icap_beam_step_f32); on != 0 returns ICAP_ERR_UNSUPPORTED for a shape
+ * that is not served.  icap_engine_fused_vocab reports the current choice.  No
+ * counterpart in the reference. */
+int icap_engine_set_fused_vocab(icap_engine* engine, int on);
+int icap_engine_fused_vocab(const icap_engine* engine);
 int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
                              int32_t* launches /*[ICAP_K_COUNT]*/);
 

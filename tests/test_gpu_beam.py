@@ -307,3 +307,71 @@ def test_helper_functions_match_oracle(bs):
     np.testing.assert_array_equal(np_of(bs.batch_gather(to_dev(ai), to_dev(idx))), co.batch_gather(ai, idx))
     with pytest.raises(IndexError):
         bs.batch_gather(to_dev(a), to_dev(np.full((5, 1), 9, np.int32)))
+
+
+# ---- fused vocab projection + beam step (no logits in memory) ----
+
+@pytest.mark.parametrize("B,W,K,V,t,eos", [
+    (4, 3, 64, 10000, 2, 4), (3, 3, 64, 10000, 0, 4), (5, 1, 32, 1000, 3, 4), (3, 5, 96, 5000, 4, 4),
+    (2, 3, 32, 132, 1, 4),        # last 128-column tile has 4 valid columns, its second half none
+    (2, 2, 32, 64, 2, 70),        # eos outside the vocabulary
+    (70, 3, 64, 1028, 5, 1027)])  # several row tiles, eos in the last column
+def test_projection_topk_records_equal_unfused_step(bs, B, W, K, V, t, eos):
+    from image_caption_amd import ops
+    rng = np.random.default_rng(B * 31 + W * 7 + V + t)
+    N = B * W
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    w = (rng.standard_normal((K, V)) * 0.3).astype(np.float32)
+    w[:, 7] = w[:, 3]                       # an exact tie inside one half tile
+    if V > 200:
+        w[:, 150] = w[:, 3]                 # and across tiles
+    bias = rng.standard_normal(V).astype(np.float32) * 0.1
+    bias[7] = bias[3]
+    if V > 200:
+        bias[150] = bias[3]
+    state = _random_state(rng, B, W, t)
+    lp, fin, ln = to_dev(state.log_probs), to_dev(state.finished.astype(np.uint8)), to_dev(state.lengths)
+    top_k = 1 if W == 1 else (3 if W <= 3 else 5)
+    logits = ops.dense(to_dev(x), to_dev(w), to_dev(bias))
+    ref = ops.beam_step(logits.reshape(B, W, V), lp, fin, ln, t, eos, 1.0)
+    rec, eos_x = ops.dense_topk(to_dev(x), to_dev(w), to_dev(bias), eos, top_k)
+    got = ops.beam_step_from_records(rec, eos_x, lp, fin, ln, t, eos, 1.0, V)
+    names = ["scores", "ids", "parents", "next_log_probs", "next_finished", "next_lengths"]
+    for name, g, r in zip(names, got, ref):
+        g, r = np_of(g), np_of(r)
+        if g.dtype == np.float32:
+            with np.errstate(over="ignore"):
+                assert_close(np.maximum(g, -1e30), np.maximum(r, -1e30), rtol=2e-6, what=name)
+        else:
+            np.testing.assert_array_equal(g, r, err_msg=name)
+    # the records themselves: max and best logit of every half tile against the logits
+    lg = np_of(logits)
+    recs = np_of(rec)
+    ht = recs.shape[1]
+    pad = np.full((N, ht * 64), -np.inf, np.float32)
+    pad[:, :V] = lg
+    tiles = pad.reshape(N, ht, 64)
+    np.testing.assert_array_equal(recs[:, :, 0], tiles.max(axis=2))
+    np.testing.assert_array_equal(recs[:, :, 2], tiles.max(axis=2))
+    cols = recs[:, :, 2 + top_k].view(np.int32)
+    want = np.where(np.isfinite(tiles.max(axis=2)), tiles.argmax(axis=2) + 64 * np.arange(ht)[None], 0x7fffffff)
+    np.testing.assert_array_equal(cols, want)
+    if 0 <= eos < V:
+        np.testing.assert_array_equal(np_of(eos_x), lg[:, eos])
+    if not 0 <= eos < V:
+        return
+    # and against the oracle
+    out_o, st_o = co.beam_search_step_batch(t, lg.reshape(B, W, V), state,
+                                            co.BeamSearchConfig(W, V, eos, 1.0, co.choose_top_k))
+    np.testing.assert_array_equal(np_of(got[1]), out_o.predicted_ids)
+    np.testing.assert_array_equal(np_of(got[2]), out_o.beam_parent_ids)
+    np.testing.assert_array_equal(np_of(got[5]), st_o.lengths)
+
+
+def test_projection_topk_rejects_unsupported(bs):
+    from image_caption_amd import ops
+    x = torch.zeros(4, 32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.dense_topk(x, torch.zeros(32, 64, device="cuda"), None, 4, 2)
+    with pytest.raises(RuntimeError, match="N % 4"):
+        ops.dense_topk(x, torch.zeros(32, 65, device="cuda"), None, 4, 3)

@@ -216,3 +216,36 @@ def test_module_loop_equals_fused_engine():
     path = torch.cat(bs.loc_optimal_beam_path_batch(seq), dim=1).to(torch.int32)
     fused = sequence_beam_search(enc, dec, img, W, T, 3, 4, tile_mode="reference")
     np.testing.assert_array_equal(np_of(path), np_of(fused))
+
+
+def test_fused_and_unfused_vocab_paths_agree():
+    """The engine's fused projection + beam step (no logits buffer) against its unfused
+    kernels on the same inputs: the same records at every step."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = co.perturb_biases(co.make_params(5, 128, 64, 64, 64, 1000), 6)
+    img = to_dev(co.make_images(7, 12, 16, 128))
+    cfg = CaptionConfig(B=12, W=3, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=10, start_id=3,
+                        eos_id=4)
+    eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+    assert eng.fused_vocab                       # this shape qualifies for the fused path
+    outs = []
+    for on in (True, False):
+        eng.set_fused_vocab(on)
+        tok, best = eng.decode(img)
+        tr = eng.trace()
+        outs.append(dict(tok=np_of(tok), best=np_of(best), ids=np_of(tr["ids"]),
+                         parents=np_of(tr["parents"]), scores=np_of(tr["scores"]),
+                         lp=np_of(tr["log_probs"])))
+    a, b = outs
+    for k in ("tok", "ids", "parents"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("best", "scores", "lp"):
+        np.testing.assert_allclose(np.maximum(a[k], -1e30), np.maximum(b[k], -1e30), rtol=3e-6,
+                                   err_msg=k)
+    # a beam wider than 5 is served by the unfused kernels only
+    cfg8 = CaptionConfig(B=2, W=8, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=3, start_id=3,
+                         eos_id=4)
+    eng8 = CaptionEngine(cfg8, {k: to_dev(v) for k, v in p.items()})
+    assert not eng8.fused_vocab
+    with pytest.raises(RuntimeError):
+        eng8.set_fused_vocab(True)
