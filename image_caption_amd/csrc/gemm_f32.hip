@@ -470,6 +470,133 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
 }
 
 // ---------------------------------------------------------------------------------
+// Small projections (a few hundred 64x64 tiles at most, e.g. [1536,512] x [512,512]): with
+// one tile per compute unit the K loop is a chain of short steps whose latency (barrier,
+// LDS round trip, global loads) is not hidden by other workgroups.  This form puts KS
+// groups of four waves on every tile; group ks multiplies every KS-th slice of 8 k values
+// of each 64-deep K step, so a step costs each wave 1/KS of the matrix work, and the KS
+// partial tiles are summed through LDS at the end.  K % 64 == 0, aligned operands.
+// ---------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256 * KS, 1) void dense_f32_small_kernel(DenseArgs p) {
+  constexpr int BM = 64, BN = 64, KB = 64, NT = 256 * KS;
+  constexpr int A_LD = (BM * KB / 4) / NT;
+  constexpr int B_LD = (KB * BN / 4) / NT;
+  constexpr int NG = KB / 8;  // slices of 8 k per step
+  static_assert(NG % KS == 0 && A_LD >= 1 && B_LD >= 1, "bad split");
+  struct Stage {
+    float4 As[2][KB / 4][BM + 1];
+    float Bs[2][KB][BN];
+  };
+  union Lds {
+    Stage st;
+    float red[KS > 1 ? (KS - 1) * 4 * 16 * 64 : 1];  // partial tiles of groups 1..KS-1
+  };
+  __shared__ Lds lds;
+  auto& As = lds.st.As;
+  auto& Bs = lds.st.Bs;
+
+  int tile_m, tile_n;
+  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ks = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int off_a[A_LD], off_b[B_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int f = tid + i * NT;
+    const int gm = min(m0 + f / (KB / 4), p.M - 1);
+    off_a[i] = gm * p.lda + 4 * (f % (KB / 4));
+  }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int f = tid + i * NT;
+    const int col = min(n0 + 4 * (f % (BN / 4)), p.N - 4);
+    off_b[i] = (f / (BN / 4)) * p.ldb + col;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  float4 ra[A_LD], rb[B_LD];
+#define ICAP_SM_LOAD(a_tile_, b_tile_)                                                \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                            \
+      *reinterpret_cast<const float4*>((a_tile_) + off_a[i]);                         \
+  _Pragma("unroll") for (int i = 0; i < B_LD; ++i) rb[i] =                            \
+      *reinterpret_cast<const float4*>((b_tile_) + off_b[i]);
+#define ICAP_SM_STORE(buf_)                                                           \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                  \
+    const int f = tid + i * NT;                                                       \
+    As[buf_][f % (KB / 4)][f / (KB / 4)] = ra[i];                                     \
+  }                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                  \
+    const int f = tid + i * NT;                                                       \
+    *reinterpret_cast<float4*>(&Bs[buf_][f / (BN / 4)][4 * (f % (BN / 4))]) = rb[i];  \
+  }
+
+  const int nk = p.K / KB;
+  const float* a_tile = p.A;
+  const float* b_tile = p.B;
+  ICAP_SM_LOAD(a_tile, b_tile)
+  ICAP_SM_STORE(0)
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < nk;
+    a_tile += more ? KB : 0;
+    b_tile += more ? (size_t)KB * p.ldb : 0;
+    ICAP_SM_LOAD(a_tile, b_tile)
+#pragma unroll
+    for (int gg = 0; gg < NG / KS; ++gg) {
+      const int g = gg * KS + ks;
+      const float4 a = As[buf][2 * g + half][wm * 32 + l31];
+      float b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = Bs[buf][8 * g + 4 * half + q][wn * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+    }
+    ICAP_SM_STORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef ICAP_SM_LOAD
+#undef ICAP_SM_STORE
+
+  // sum the partial tiles: groups 1.. park theirs in LDS (staging is idle), group 0 adds
+  if (KS > 1) {
+    if (ks > 0) {
+      float* dst = lds.red + ((ks - 1) * 4 + (wave & 3)) * 16 * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int q = 1; q < KS; ++q) {
+      const float* src = lds.red + ((q - 1) * 4 + (wave & 3)) * 16 * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += src[r * 64 + lane];
+    }
+  }
+  const int col = n0 + wn * 32 + l31;
+  if (col >= p.N) return;
+  const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row < p.M) {
+      float v = acc[r] + bv;
+      if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+      p.C[(size_t)row * p.ldc + col] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // LSTM step.  N = B*W rows is small (1536 at the headline shape), so the output is cut
 // into many small units to fill 1024 SIMDs evenly: a workgroup owns 32 rows x 32 hidden
 // units, and its four waves each own ONE gate (i, f, g, o) of that patch - one 32x32
@@ -883,6 +1010,23 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
   // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
   if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 3>(a, vec, s);
+  {
+    // few tiles: the split-K form of the 64x64 tile (tuning knob ICAP_SMALL_KS = 1|2|4)
+    static const char* ks_env = getenv("ICAP_SMALL_KS");
+    const int ks = ks_env ? atoi(ks_env) : 2;
+    const long tiles64 = (long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (ks > 1 && vec && K % 64 == 0 && N >= 4 && tiles64 <= 512 &&
+        (long long)M * K < (1LL << 31) && (long long)K * N < (1LL << 31)) {
+      a.tiles_m = ceil_div(M, 64);
+      a.tiles_n = ceil_div(N, 64);
+      if (ks >= 4)
+        hipLaunchKernelGGL(dense_f32_small_kernel<4>, dim3((unsigned)tiles64), dim3(1024), 0, s, a);
+      else
+        hipLaunchKernelGGL(dense_f32_small_kernel<2>, dim3((unsigned)tiles64), dim3(512), 0, s, a);
+      ICAP_LAUNCH_CHECK("dense_f32_small_kernel");
+      return ICAP_OK;
+    }
+  }
   return launch_dense<64, 64, 2, 2, 2>(a, vec, s);
 }
 
