@@ -32,7 +32,8 @@ struct DenseArgs {
   int lda, ldb, ldc;
   int act;
   int tiles_m, tiles_n;
-  int band_order;  // tile order: 0 = down a column of tiles, 1 = across a band of panels
+  int band_order;  // tile order: 0 = down a column of tiles, 1 = a band of panels per XCD,
+                   // 2 = a band of tile rows per XCD (small kernels)
   // top-k epilogue (dense_topk_f32): per (row, 64-column half tile) records instead of C
   float* rec;    // [M][2*tiles_n][2 + 2*WL]: max, sum exp(x - max), WL best x, WL columns
   float* eos_x;  // [M]: the logit of column `eos`
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(256 * KS, 1) void dense_f32_small_kernel(DenseArgs 
   auto& Bs = lds.st.Bs;
 
   int tile_m, tile_n;
-  tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  if (p.band_order == 2) tile_of_block_rowband(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  else tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ks = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
@@ -581,6 +583,102 @@ __global__ __launch_bounds__(256 * KS, 1) void dense_f32_small_kernel(DenseArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += src[r * 64 + lane];
     }
+  }
+  const int col = n0 + wn * 32 + l31;
+  if (col >= p.N) return;
+  const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row < p.M) {
+      float v = acc[r] + bv;
+      if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+      p.C[(size_t)row * p.ldc + col] = v;
+    }
+  }
+}
+
+// Short-K form of the small projections (K = 64*NK <= 512): 16 waves per 64x64 tile and
+// EVERY global load of the tile's K loop issued before the first multiply (one float4 of
+// A and one of B per thread and K step, NK of each held in registers), so the loop pays the
+// memory latency once instead of once per step.  Group ks of four waves multiplies slices
+// ks and ks+4 of each 64-deep step; the four partial tiles are summed through LDS.
+template <int NK>
+__global__ __launch_bounds__(1024, 1) void dense_f32_shortk_kernel(DenseArgs p) {
+  constexpr int BM = 64, BN = 64, KB = 64, KS = 4;
+  struct Stage {
+    float4 As[2][KB / 4][BM + 1];
+    float Bs[2][KB][BN];
+  };
+  union Lds {
+    Stage st;
+    float red[(KS - 1) * 4 * 16 * 64];
+  };
+  __shared__ Lds lds;
+  auto& As = lds.st.As;
+  auto& Bs = lds.st.Bs;
+
+  int tile_m, tile_n;
+  if (p.band_order == 2) tile_of_block_rowband(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  else tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ks = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // thread -> one float4 of the A tile (row a_m, k quad a_q) and one of the B tile
+  const int a_q = tid % (KB / 4), a_m = tid / (KB / 4);
+  const int b_c = 4 * (tid % (BN / 4)), b_k = tid / (BN / 4);
+  const float* a_ptr = p.A + (size_t)min(m0 + a_m, p.M - 1) * p.lda + 4 * a_q;
+  const float* b_ptr = p.B + (size_t)b_k * p.ldb + min(n0 + b_c, p.N - 4);
+  static_assert(NK == 4 || NK == 8, "short-K form is built for K = 256 and K = 512");
+  // (named registers, not arrays: an array of 8 float4 is not split into registers here)
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define ICAP_SK_LOAD(T)                                                 \
+  ra##T = *reinterpret_cast<const float4*>(a_ptr + (T) * KB);           \
+  rb##T = *reinterpret_cast<const float4*>(b_ptr + (size_t)(T) * KB * p.ldb);
+  ICAP_SK_LOAD(0) ICAP_SK_LOAD(1) ICAP_SK_LOAD(2) ICAP_SK_LOAD(3)
+  if constexpr (NK == 8) { ICAP_SK_LOAD(4) ICAP_SK_LOAD(5) ICAP_SK_LOAD(6) ICAP_SK_LOAD(7) }
+#undef ICAP_SK_LOAD
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // one barrier per step: buffer buf^1 is rewritten only after the next barrier
+#define ICAP_SK_STEP(T)                                                                  \
+  {                                                                                      \
+    constexpr int buf = (T) & 1;                                                         \
+    As[buf][a_q][a_m] = ra##T;                                                           \
+    *reinterpret_cast<float4*>(&Bs[buf][b_k][b_c]) = rb##T;                              \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int gg = 0; gg < 2; ++gg) {                                   \
+      const int g = gg * KS + ks;                                                        \
+      const float4 a = As[buf][2 * g + half][wm * 32 + l31];                             \
+      float b[4];                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q)                                      \
+          b[q] = Bs[buf][8 * g + 4 * half + q][wn * 32 + l31];                           \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);               \
+    }                                                                                    \
+  }
+  ICAP_SK_STEP(0) ICAP_SK_STEP(1) ICAP_SK_STEP(2) ICAP_SK_STEP(3)
+  if constexpr (NK == 8) { ICAP_SK_STEP(4) ICAP_SK_STEP(5) ICAP_SK_STEP(6) ICAP_SK_STEP(7) }
+#undef ICAP_SK_STEP
+  __syncthreads();  // staging is idle from here on
+  if (ks > 0) {
+    float* dst = lds.red + ((ks - 1) * 4 + (wave & 3)) * 16 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks > 0) return;
+#pragma unroll
+  for (int q = 1; q < KS; ++q) {
+    const float* src = lds.red + ((q - 1) * 4 + (wave & 3)) * 16 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += src[r * 64 + lane];
   }
   const int col = n0 + wn * 32 + l31;
   if (col >= p.N) return;
@@ -1019,7 +1117,17 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
         (long long)M * K < (1LL << 31) && (long long)K * N < (1LL << 31)) {
       a.tiles_m = ceil_div(M, 64);
       a.tiles_n = ceil_div(N, 64);
-      if (ks >= 4)
+      // row bands per XCD when A is the larger operand (tuning knob ICAP_SMALL_ORDER=col|row)
+      static const char* so_env = getenv("ICAP_SMALL_ORDER");
+      a.band_order = (M >= N) ? 2 : 0;
+      if (so_env) a.band_order = so_env[0] == 'r' ? 2 : 0;
+      static const char* sk_env = getenv("ICAP_SHORTK");  // tuning knob: "0" disables
+      const bool shortk = !(sk_env && sk_env[0] == '0');
+      if (shortk && K == 512)
+        hipLaunchKernelGGL(dense_f32_shortk_kernel<8>, dim3((unsigned)tiles64), dim3(1024), 0, s, a);
+      else if (shortk && K == 256)
+        hipLaunchKernelGGL(dense_f32_shortk_kernel<4>, dim3((unsigned)tiles64), dim3(1024), 0, s, a);
+      else if (ks >= 4)
         hipLaunchKernelGGL(dense_f32_small_kernel<4>, dim3((unsigned)tiles64), dim3(1024), 0, s, a);
       else
         hipLaunchKernelGGL(dense_f32_small_kernel<2>, dim3((unsigned)tiles64), dim3(512), 0, s, a);

@@ -129,6 +129,14 @@ __device__ __forceinline__ void tile_of_block_band(int pid, int tiles_m, int til
   tm = in_band / width;
   tn = band * pw + in_band % width;
 }
+
+// Row-band variant: every XCD owns a band of ceil(tiles_m/8) tile rows and sweeps it with
+// the tile row fastest, so the A operand is fetched by one XCD only and B by all eight -
+// the order for small products whose A operand was just written by the previous kernel.
+__device__ __forceinline__ void tile_of_block_rowband(int pid, int tiles_m, int tiles_n, int& tm,
+                                                      int& tn) {
+  tile_of_block_band(pid, tiles_n, tiles_m, tn, tm);
+}
 #endif
 
 }  // namespace icap
