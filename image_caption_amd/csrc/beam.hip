@@ -701,19 +701,18 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
   }
 
   // Threads 0..W-1 finish one successor each.  The next-state buffers may be the state
-  // inputs: every thread reads what it needs, then a barrier, then the stores.
+  // inputs: every read of the state happened before the barriers of the rounds above.
   const bool act = tid < W;
   const int flat = (my_i == EMPTY_IDX) ? 0 : my_i;
   const int word = flat % V;
   const int parent = flat / V;
-  int nfin = 0, nlen = 0;
-  if (act) {
-    const size_t rp = row0 + parent;
-    const int pfin = p.finished[rp] ? 1 : 0;
-    nfin = (pfin || word == p.eos) ? 1 : 0;
-    nlen = p.lengths[rp] + ((word != p.eos && !nfin) ? 1 : 0);
-  }
-  __syncthreads();
+  // the parent's state is already in registers (rows beyond n_rows cannot be parents)
+  int pfin = 0, plen = 0;
+#pragma unroll
+  for (int q = 0; q < MAXW; ++q)
+    if (q == parent) { pfin = fin_r[q] ? 1 : 0; plen = len_r[q]; }
+  const int nfin = (pfin || word == p.eos) ? 1 : 0;
+  const int nlen = plen + ((word != p.eos && !nfin) ? 1 : 0);
   if (act) {
     const size_t o = row0 + tid;
     p.scores[o] = my_s;

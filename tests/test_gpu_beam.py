@@ -351,13 +351,23 @@ def test_projection_topk_records_equal_unfused_step(bs, B, W, K, V, t, eos):
     pad = np.full((N, ht * 64), -np.inf, np.float32)
     pad[:, :V] = lg
     tiles = pad.reshape(N, ht, 64)
-    np.testing.assert_array_equal(recs[:, :, 0], tiles.max(axis=2))
-    np.testing.assert_array_equal(recs[:, :, 2], tiles.max(axis=2))
+    # (ops.dense may pick a split-K kernel for this shape, so its sums can differ from the
+    # projection's by an ulp or two: compare values with the fp32 bar, columns through values)
+    tmax = tiles.max(axis=2)
+    live = np.isfinite(tmax)
+    assert_close(np.where(live, recs[:, :, 0], 0), np.where(live, tmax, 0), what="record max")
+    np.testing.assert_array_equal(recs[:, :, 2], recs[:, :, 0])
+    assert (np.isneginf(recs[:, :, 0]) == ~live).all()
     cols = recs[:, :, 2 + top_k].view(np.int32)
-    want = np.where(np.isfinite(tiles.max(axis=2)), tiles.argmax(axis=2) + 64 * np.arange(ht)[None], 0x7fffffff)
-    np.testing.assert_array_equal(cols, want)
+    assert (cols[~live] == 0x7fffffff).all()
+    cl = np.where(live, cols, 0)
+    assert ((cl >= 0) & (cl < V)).all() and ((cl // 64) == np.arange(ht)[None])[live].all()
+    at_col = np.take_along_axis(lg, cl.reshape(N, -1), axis=1).reshape(N, ht)
+    assert_close(np.where(live, at_col, 0), np.where(live, tmax, 0), what="logit at the recorded column")
+    ssum = np.where(live, np.exp(tiles - np.where(live, tmax, 0)[..., None]).sum(axis=2), 0)
+    assert_close(np.where(live, recs[:, :, 1], 0), ssum, what="record sum exp")
     if 0 <= eos < V:
-        np.testing.assert_array_equal(np_of(eos_x), lg[:, eos])
+        assert_close(np_of(eos_x), lg[:, eos], what="eos logit")
     if not 0 <= eos < V:
         return
     # and against the oracle

@@ -64,6 +64,11 @@ def main():
         out = torch.empty(M, Nn, device=dev)
         run(name, lambda: ops.dense(x, w, b, act=act, out=out), flops=2.0 * M * K * Nn)
 
+    # vocab projection with the fused top-k epilogue (no logits written)
+    x, w, b = rn(N, H), rn(H, V) * 0.05, rn(V)
+    run("topk vocab", lambda: ops.dense_topk(x, w, b, 4, 1 if W == 1 else (3 if W <= 3 else 5)),
+        flops=2.0 * N * H * V)
+
     # the same contractions with bf16 operands
     for name, (M, K, Nn, act) in {
             "bf16 encode": (B * L, F, D, 1), "bf16 fc1": (N, H, H, 0), "bf16 vocab": (N, H, V, 0)}.items():
