@@ -184,7 +184,15 @@ def main():
                      "launches": n_vocab})
         ms_beam, n_beam = ktimes["beam"]
         ms_att, n_att = ktimes["attention"]
-        beam_gbs = (N * cfg["V"] * 4.0) / (ms_beam / max(n_beam, 1) * 1e-3) / 1e9 if ms_beam else 0
+        # the beam step reads the [N,V] logits once (unfused kernels) or the projection's
+        # top-k records, 8..12 floats per 64 logits (fused path: latency-bound, few bytes)
+        fused = eng.fused_vocab
+        if fused:
+            tk = 1 if cfg["W"] == 1 else (3 if cfg["W"] <= 3 else 5)
+            beam_bytes = N * (2 * ((cfg["V"] + 127) // 128)) * (2 + 2 * tk) * 4.0
+        else:
+            beam_bytes = N * cfg["V"] * 4.0
+        beam_gbs = beam_bytes / (ms_beam / max(n_beam, 1) * 1e-3) / 1e9 if ms_beam else 0
         att_bytes = cfg["B"] * cfg["L"] * (cfg["U"] + cfg["D"]) * 4.0 + N * (cfg["U"] + cfg["D"] + cfg["L"]) * 4.0
         att_gbs = att_bytes / (ms_att / max(n_att, 1) * 1e-3) / 1e9 if ms_att else 0
         line = {
@@ -198,7 +206,10 @@ def main():
                        "hidden": cfg["H"], "vocab": cfg["V"], "tile_mode": args.tile_mode,
                        "sharding": "images split over ranks, all-gather of sequences"},
             "roofline": roof,
-            "hbm_kernels": {"beam_step_GBps": round(beam_gbs, 1), "attention_GBps": round(att_gbs, 1),
+            "hbm_kernels": {"beam_step_GBps": round(beam_gbs, 1),
+                            "beam_step_path": "top-k records of the fused projection" if fused
+                            else "logits read once",
+                            "beam_step_bytes": int(beam_bytes), "attention_GBps": round(att_gbs, 1),
                             "peak_GBps": PEAK_HBM_GBS},
             "kernel_ms_per_step": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
         }

@@ -18,7 +18,7 @@ def classify(name, grid, block):
     if "dense_f32_fast_kernel<128" in name:
         topk = not name.rstrip(")").rstrip("(icap::(anonymous namespace)::DenseArgs").endswith(", 0>")
         return "vocab_projection" if (topk or grid // max(block, 1) == 948) else "dense128_other"
-    for key, cls in (("dense_f32_small_kernel", "small_dense"), ("dense_f32_fast_kernel<64", "small_dense"),
+    for key, cls in (("dense_f32_small_kernel", "small_dense"), ("dense_f32_shortk_kernel", "small_dense"), ("dense_f32_fast_kernel<64", "small_dense"),
                      ("lstm_f32", "lstm"), ("attention_f32", "attention"), ("beam_records", "beam_records"),
                      ("beam_row", "beam_row"), ("beam_merge", "beam_merge"), ("gemm_bf16", "gemm_bf16")):
         if key in name:
@@ -31,12 +31,13 @@ def main():
     rnd = sys.argv[2] if len(sys.argv) > 2 else "r1"
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    newest = lambda paths: sorted(paths, key=os.path.getmtime)[-1:]   # merged runs pile up locally
+    stats = newest(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "bench_kernel_stats.csv"))
     res = {}
     for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+        files = newest(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")))
         if not files:
             continue
         agg = collections.defaultdict(list)
