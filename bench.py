@@ -67,17 +67,25 @@ def cpu_baseline(cfg, budget_s=12.0):
     p = co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"])
     img = co.make_images(1, Bs, cfg["L"], cfg["F"])
     co.predict_image_caption_sequence(p, img[:4], cfg["W"], 2, 3, 4)      # warm the BLAS pool
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        co.predict_image_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, 1.0, "reference")
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 50:
-            break
+    def rate(hoist, budget):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            co.predict_image_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, 1.0, "reference",
+                                              hoist_w1=hoist)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or reps >= 50:
+                return reps, el
+    reps, el = rate(False, budget_s)
+    reps_h, el_h = rate(True, budget_s / 2)       # W1(features) hoisted out of the step loop
     return {"value": round(Bs * reps / el, 2), "unit": "captions/s", "cores": threads,
             "kind": "port",
             "sample": "%d decodes of B=%d images (beam %d, %d steps, V=%d), numpy oracle, %.1f s"
-                      % (reps, Bs, cfg["W"], cfg["T"], cfg["V"], el)}
+                      % (reps, Bs, cfg["W"], cfg["T"], cfg["V"], el),
+            "hoisted_value": round(Bs * reps_h / el_h, 2),
+            "hoisted_note": "same oracle with the step-invariant W1(features) computed once per "
+                            "decode, so that the ratio is not inflated by that inefficiency of "
+                            "the reference loop"}
 
 
 def main():

@@ -70,12 +70,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   for (int ch = 0; ch < UCH; ++ch) v4[ch] = ld4<VEC>(p.v, ch * 256 + lane * 4, p.U);
 
   // a workgroup walks groups g, g + gridDim.x, ... (the grid may be capped, see attention_f32)
-  for (int g = blockIdx.x; g < p.G; g += gridDim.x) {
+  // and every block of RB rows of a group is its own work item: rows only share reads
+  const int n_blk = (p.R + RB - 1) / RB;
+  for (int wi = blockIdx.x; wi < p.G * n_blk; wi += gridDim.x) {
+  const int g = wi / n_blk;
+  const int kb = (wi - g * n_blk) * RB;             // first row of this work item
+  const int ke = min(kb + RB, p.R);                 // one past its last row
   const float* pf_g = p.pf + (size_t)g * p.L * p.U;
   const float* f_g = p.features + (size_t)g * p.L * p.D;
 
-  // beta gate per row (wave k % 4 computes row k)
-  for (int k = wave; k < p.R; k += ATT_WAVES) {
+  // beta gate per row (one wave per row)
+  for (int k = kb + wave; k < ke; k += ATT_WAVES) {
     float beta = 1.f;
     if (p.gate_state) {
       const int n = g * p.stride_g + k * p.stride_k;
@@ -89,11 +94,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   }
 
   // ---- phase 1: scores ----
-  for (int k0 = 0; k0 < p.R; k0 += RB) {
+  {
+    const int k0 = kb;
     float4 q4[RB][UCH];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int k = min(k0 + r, p.R - 1);
+      const int k = min(k0 + r, ke - 1);
       const int n = g * p.stride_g + k * p.stride_k;
 #pragma unroll
       for (int ch = 0; ch < UCH; ++ch)
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         part[r] = 0.f;
-        if (k0 + r >= p.R) continue;  // uniform: the last pass may hold fewer rows
+        if (k0 + r >= ke) continue;  // uniform: the last block may hold fewer rows
         float a = 0.f;
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch) {
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int k = k0 + r;
-          if (k < p.R) {
+          if (k < ke) {
             float sc = part[r] + p.bv;
             if (p.score_bias) {
               const int n = g * p.stride_g + k * p.stride_k;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   __syncthreads();
 
   // ---- phase 2: softmax over l, one wave per row ----
-  for (int k = wave; k < p.R; k += ATT_WAVES) {
+  for (int k = kb + wave; k < ke; k += ATT_WAVES) {
     float m = -INFINITY;
     for (int l = lane; l < p.L; l += 64) m = fmaxf(m, s_w[k * p.L + l]);
     m = wave_max(m);
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   __syncthreads();
 
   // ---- phase 3: context ----
-  for (int k0 = 0; k0 < p.R; k0 += RB) {
+  {
+    const int k0 = kb;
     for (int d0 = 0; d0 < p.D; d0 += 256) {
       const int d = d0 + lane * 4;
       float4 acc[RB];
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
         const float4 f = ld4<VEC>(f_g + (size_t)l * p.D, d, p.D);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-          const float w = s_w[min(k0 + r, p.R - 1) * p.L + l];
+          const float w = s_w[min(k0 + r, ke - 1) * p.L + l];
           acc[r].x += w * f.x;
           acc[r].y += w * f.y;
           acc[r].z += w * f.z;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
         const int r = idx / span;
         const int e = d0 + idx % span;
         const int k = k0 + r;
-        if (k < p.R) {
+        if (k < ke) {
           float sum = 0.f;
 #pragma unroll
           for (int w = 0; w < ATT_WAVES; ++w) sum += s_part[(w * RB + r) * dpad + e];
@@ -286,7 +293,7 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
   ICAP_REQUIRE(!gate_state || H > 0, "attention_f32: H must be positive with a gate");
   AttArgs a{pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
             G, R, stride_g, stride_k, L, U, D, H,
-            (max_workgroups > 0 && max_workgroups < G) ? max_workgroups : G};
+            0};
   const bool vec = (U % 4 == 0) && (D % 4 == 0) && aligned16(pf) && aligned16(features) &&
                    aligned16(q) && aligned16(v);
   // rows held in registers per pass over PF: the fewest passes, then the fewest idle slots
@@ -300,6 +307,8 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
       }
     }
   }
+  a.grid = G * ceil_div(R, rb);  // one work item per (group, block of rb rows)
+  if (max_workgroups > 0 && max_workgroups < a.grid) a.grid = max_workgroups;
   const int dpad = ((D + 3) / 4) * 4;
   const size_t smem =
       sizeof(float) * ((size_t)((R * L + 3) / 4) * 4 + ATT_MAX_ROWS + (size_t)ATT_WAVES * rb * dpad);

@@ -97,13 +97,15 @@ def feature_proj_state(features, kernel, bias, mask=None):
     return dense(pooled, kernel, bias)
 
 
-def bahdanau_attention(features, hidden, p, bias=None):
+def bahdanau_attention(features, hidden, p, bias=None, w1f=None):
     """`BahdanauAttention.call` (`attention/attention.py:40-65`).
 
     score = V(tanh(W1(features) + W2(hidden)[:,None,:])) (+ bias[:, :, None]);
     weights = softmax over the L axis; context = sum_L weights * features.
-    Returns (context[N,D], weights[N,L,1])."""
-    w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"])            # [N,L,U]
+    Returns (context[N,D], weights[N,L,1]).  `w1f` lets a caller pass W1(features)
+    computed once (it does not depend on the step); the reference recomputes it."""
+    if w1f is None:
+        w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"])        # [N,L,U]
     w2h = dense(hidden[:, None, :], p["att_W2_kernel"], p["att_W2_bias"])  # [N,1,U]
     act = np.tanh(w1f + w2h)
     score = dense(act, p["att_V_kernel"], p["att_V_bias"])                 # [N,L,1]
@@ -130,7 +132,7 @@ def lstm_cell(x, h_tm1, c_tm1, kernel, recurrent_kernel, bias):
     return h, [h, c]
 
 
-def lstm_decoder_step(p, dec_input, features, hidden, bias=None):
+def lstm_decoder_step(p, dec_input, features, hidden, bias=None, w1f=None):
     """`LstmDecoder.call` (`decoder/lstm_recurrent_decoder.py:59-116`).
 
     The attention query and the beta gate use `hidden[-1]`, which is the LSTM CELL
@@ -140,7 +142,7 @@ def lstm_decoder_step(p, dec_input, features, hidden, bias=None):
     ids = np.asarray(dec_input).reshape(-1)
     emb = embedding_lookup(p["embedding"], ids)
     h_state = hidden[-1]
-    context, weights = bahdanau_attention(features, h_state, p, bias=bias)
+    context, weights = bahdanau_attention(features, h_state, p, bias=bias, w1f=w1f)
     beta = sigmoid(dense(h_state, p["fc3_kernel"], p["fc3_bias"]))
     context = context * beta
     lstm_input = np.concatenate([context, emb], axis=-1)
@@ -364,12 +366,15 @@ def tile_features(features, beam_width, tile_mode):
 
 def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id,
                                    length_penalty_weight=1.0, tile_mode="reference",
-                                   reset_state_from_feat=1, return_trace=False):
+                                   reset_state_from_feat=1, return_trace=False,
+                                   hoist_w1=False):
     """`predict_image_caption_sequence` (`recurrent_example.py:477-562`).
 
     encoder -> tile -> reset_state -> T x (decoder step, beam step) -> back-track.
     The recurrent state is NOT reordered by parent beam between steps (`:526-529`,
     `:558`): only the token ids come from the beam search.  No early exit (`:517`).
+    `hoist_w1` computes the step-invariant W1(features) once instead of every step (same
+    values; a faster CPU variant used as a second baseline by the benchmark).
     Returns int32 tokens [B,T] (and the per-step trace if asked)."""
     B = img.shape[0]
     W = beam_width
@@ -382,8 +387,9 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     config = BeamSearchConfig(W, V, eos_id, length_penalty_weight, choose_top_k)
     seq = []
     trace = []
+    w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"]) if hoist_w1 else None
     for i in range(max_len):
-        logits, hidden, weights, ctx = lstm_decoder_step(p, dec_input, features, hidden)
+        logits, hidden, weights, ctx = lstm_decoder_step(p, dec_input, features, hidden, w1f=w1f)
         logits3 = logits.reshape(-1, W, V)
         out, state = beam_search_step_batch(i, logits3, state, config)
         seq.append((out, state))

@@ -119,3 +119,11 @@ def test_driver_repeat_mode_is_per_image_independent():
     for b in range(5):
         one = co.predict_image_caption_sequence(p, img[b:b + 1], 3, 7, 3, 4, tile_mode="repeat")
         np.testing.assert_array_equal(full[b], one[0])
+
+
+def test_hoisted_w1_variant_gives_the_same_tokens():
+    p = co.perturb_biases(co.make_params(2, 24, 8, 8, 16, 50), 3)
+    img = co.make_images(4, 3, 5, 24)
+    a = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4)
+    b = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4, hoist_w1=True)
+    np.testing.assert_array_equal(a, b)
