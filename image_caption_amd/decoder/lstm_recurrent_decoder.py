@@ -190,7 +190,7 @@ class LstmDecoder(Decoder):
             self.embedding_layer.table  # noqa: B018  builds the table
         return None
 
-    # -- weight import / export with the oracle's parameter names --
+    # -- weight import / export with the .npz container's parameter names --
     def load_params(self, p, device=None):
         dev = device or self.device or default_device()
         self.lstm.set_weights(p["lstm_kernel"], p["lstm_recurrent_kernel"], p["lstm_bias"], dev)

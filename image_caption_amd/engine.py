@@ -13,7 +13,7 @@ from . import _lib, ops
 TILE_MODES = {"reference": _lib.TILE_REFERENCE, "repeat": _lib.TILE_REPEAT}
 PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}
 
-# oracle / checkpoint parameter name -> icap_weights field
+# checkpoint (.npz) parameter name -> icap_weights field
 PARAM_TO_FIELD = {
     "enc_kernel": "enc_kernel", "enc_bias": "enc_bias", "embedding": "embedding",
     "init0_kernel": "init_h_kernel", "init0_bias": "init_h_bias",

@@ -159,3 +159,34 @@ def test_weight_container_roundtrip(tmp_path):
     sy.save_params(path, p)
     q = sy.load_params(path)
     assert q.keys() == p.keys() and all(np.array_equal(p[k], q[k]) for k in p)
+
+
+def test_product_code_never_touches_the_oracle():
+    """The oracle is test infrastructure: no file of the package (Python or HIP) names it,
+    and importing the whole package leaves it unloaded."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "image_caption_amd")
+    hits = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                with open(os.path.join(d, f)) as fh:
+                    if "oracle" in fh.read():
+                        hits.append(os.path.join(d, f))
+    assert hits == []
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import image_caption_amd, image_caption_amd.engine, image_caption_amd.distributed\n"
+            "from image_caption_amd.beam_search import beam_search\n"
+            "from image_caption_amd.decoder import lstm_recurrent_decoder\n"
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)\n") % ROOT
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=120)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """No CPU fallback: without libicap.so the loader raises instead of computing elsewhere."""
+    from image_caption_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libicap.so"))
+    with pytest.raises(ImportError):
+        _lib.load()
