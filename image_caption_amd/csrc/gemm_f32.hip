@@ -225,7 +225,9 @@ constexpr int TOPK_EMPTY = 0x7fffffff;
 // the log-softmax and the top-k over the whole row need, in 2 + 2*TOPK floats per 64
 // logits, so the [M,N] logits are never written to memory.
 template <int BM, int BN, int WM, int WN, int MINW, int TOPK = 0>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(DenseArgs p) {
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+    __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
+    void dense_f32_fast_kernel(DenseArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -321,6 +323,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
       }
   };
 
+  // The prefetch of the next K step is issued through inline asm at the top of the step:
+  // written as plain loads, the scheduler sinks them to just above the LDS stores at the
+  // bottom (two MFMAs before their wait), which exposes the memory latency in every step.
+  // The compiler does not count these loads, so the wait before the stores is explicit.
+#define ICAP_LOAD_TILES_EARLY(a_tile_, b_tile_)                                                  \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                               \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"((a_tile_) + off_a[i])); \
+  _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                               \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"((b_tile_) + off_b[i]));
   const int nk = p.K / BK;
   const float* a_tile = p.A;
   const float* b_tile = p.B;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
     const bool more = t + 1 < nk;
     a_tile += more ? BK : 0;
     b_tile += more ? (size_t)BK * p.ldb : 0;
-    ICAP_LOAD_TILES(a_tile, b_tile)
+    ICAP_LOAD_TILES_EARLY(a_tile, b_tile)
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float4 a[TM];
@@ -343,9 +354,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void dense_f32_fast_kernel(Dense
       read_frags(buf, g, a, b);
       mfma_group(a, b);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ICAP_STORE_TILES(buf ^ 1)
     __syncthreads();
   }
+#undef ICAP_LOAD_TILES_EARLY
 
   if constexpr (TOPK == 0) {
 #pragma unroll
@@ -1008,6 +1021,23 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                  \
         *reinterpret_cast<const float4*>(a_ + (in_ctx_ ? off_a_ctx[i] : off_a_h[i]));         \
   }
+  // The in-loop prefetch goes through inline asm so that it stays at the top of the step
+  // (plain loads are sunk to just above the LDS stores, and with one workgroup per compute
+  // unit nothing else would cover that latency); its wait is explicit, before the stores.
+#define ICAP_LW_LOAD_EARLY(K0)                                                                \
+  {                                                                                           \
+    const int k0_ = (K0);                                                                     \
+    const bool in_ctx_ = k0_ < p.C;                                                           \
+    const float* b_ = in_ctx_ ? p.kernel + (size_t)k0_ * H4                                   \
+                              : p.recurrent + (size_t)(k0_ - p.C) * H4;                       \
+    const float* a_ = in_ctx_ ? p.ctx + k0_ : p.h + (k0_ - p.C);                              \
+    _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                          \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(b_ + off_b[i]));   \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                          \
+        asm volatile("global_load_dwordx4 %0, %1, off"                                        \
+                     : "=v"(ra[i])                                                            \
+                     : "v"(a_ + (in_ctx_ ? off_a_ctx[i] : off_a_h[i])));                      \
+  }
 #define ICAP_LW_STORE(BUF)                                                                    \
   {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                          \
@@ -1024,7 +1054,7 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    ICAP_LW_LOAD(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
+    ICAP_LW_LOAD_EARLY(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
 #pragma unroll
     for (int g = 0; g < LBK / 8; ++g) {
       const float4 a = As[buf][2 * g + half][rg * 32 + l31];
@@ -1036,9 +1066,11 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ICAP_LW_STORE(buf ^ 1)
     __syncthreads();
   }
+#undef ICAP_LW_LOAD_EARLY
 #undef ICAP_LW_LOAD
 #undef ICAP_LW_STORE
 
@@ -1111,7 +1143,7 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
   // 128x128 tiles (8 waves, 32x64 per wave, 2 workgroups = 4 waves per SIMD) when they
   // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-  if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 3>(a, vec, s);
+  if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 2>(a, vec, s);
   {
     // few tiles: the split-K form of the 64x64 tile (tuning knob ICAP_SMALL_KS = 1|2|4)
     static const char* ks_env = getenv("ICAP_SMALL_KS");
@@ -1168,11 +1200,11 @@ int dense_topk_f32(const float* x, const float* w, const float* bias, int M, int
   // SIMDs: measured 197 us against 146 us)
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   if (top_k == 1)
-    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 2, 1>), grid, block, 0, s, a);
   else if (top_k == 3)
-    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 3>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 2, 3>), grid, block, 0, s, a);
   else
-    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 3, 5>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 2, 5>), grid, block, 0, s, a);
   ICAP_LAUNCH_CHECK("dense_f32_fast_kernel<topk>");
   return ICAP_OK;
 }
