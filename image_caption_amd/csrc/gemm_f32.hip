@@ -354,7 +354,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       read_frags(buf, g, a, b);
       mfma_group(a, b);
     }
+    // the wait, then every staging register passes through an (empty) asm so that no use
+    // of it can be scheduled above the wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
     ICAP_STORE_TILES(buf ^ 1)
     __syncthreads();
   }
@@ -1067,6 +1073,10 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));  // uses stay below the wait
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
     ICAP_LW_STORE(buf ^ 1)
     __syncthreads();
   }
