@@ -34,6 +34,7 @@ CONFIGS = {
                              precision="fp32"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32-input MFMA peak of MI355X
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -177,15 +178,21 @@ def main():
         n_vocab = vocab_n
         avg_s = vocab_ms / max(vocab_n, 1) * 1e-3
         flops = 2.0 * N * cfg["H"] * cfg["V"]
-        if precision == "bf16":
+        if precision == "bf16" and not eng.fused_vocab:
             vbytes = cfg["H"] * cfg["V"] * 2.0 + N * cfg["H"] * 4.0 + N * cfg["V"] * 4.0
             achieved = vbytes / avg_s / 1e9 if avg_s > 0 else 0.0
             roof = {"bound": "hbm", "kernel": "vocab projection gemm_bf16 [N,H]x[H,V] (fp32 logits out)",
                     "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 4)}
+        elif precision == "bf16":
+            # fused with the top-k epilogue nothing of size N*V is written: matrix-pipe bound
+            achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "vocab projection gemm_bf16 [N,H]x[H,V] + top-k records",
+                    "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4)}
         else:
             achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "vocab projection dense_f32 [N,H]x[H,V]",
+            roof = {"bound": "mfma", "kernel": "vocab projection dense_f32 [N,H]x[H,V]" + (" + top-k records" if eng.fused_vocab else ""),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
         roof.update({"traffic": measured_traffic(args.config), "avg_launch_us": round(avg_s * 1e6, 2),

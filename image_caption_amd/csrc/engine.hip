@@ -42,6 +42,9 @@ bool dense_topk_supported(const float*, const float*, int, int, int, int);
 int dense_topk_f32(const float*, const float*, const float*, int, int, int, int, int, float*, float*,
                    hipStream_t);
 bool beam_records_supported(int W, int half_tiles, int top_k);
+bool dense_topk_bf16_supported(const float*, int, int, int, int);
+int dense_topk_bf16(const float*, const void*, const float*, int, int, int, int, int, float*, float*,
+                    hipStream_t);
 int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
                                const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
                                uint8_t*, int32_t*, int, int, int, hipStream_t);
@@ -274,8 +277,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
       {
         Timed tm(e, ICAP_K_VOCAB, s);
-        ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id, e->topk,
-                                e->rec, e->eos_x, s));
+        if (c.precision == ICAP_PRECISION_BF16)
+          ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
+                                   c.eos_id, e->topk, e->rec, e->eos_x, s));
+        else
+          ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
+                                  e->topk, e->rec, e->eos_x, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s));
       Timed tm(e, ICAP_K_BEAM, s);
@@ -498,10 +505,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   {
     static const char* fused_env = getenv("ICAP_FUSED_TOPK");
     const int tk = c.W <= 1 ? 1 : (c.W <= 3 ? 3 : 5);
-    const bool shape_ok = c.precision == ICAP_PRECISION_FP32 && c.W <= 5 &&
-                          dense_topk_supported(weights->fc2_kernel, weights->fc2_kernel, (int)N, c.H,
-                                               c.V, tk) &&
-                          beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
+    const bool gemm_ok =
+        c.precision == ICAP_PRECISION_BF16
+            ? dense_topk_bf16_supported(weights->fc2_kernel, (int)N, c.H, c.V, tk)
+            : dense_topk_supported(weights->fc2_kernel, weights->fc2_kernel, (int)N, c.H, c.V, tk);
+    const bool shape_ok =
+        c.W <= 5 && gemm_ok && beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
     e->topk_able = shape_ok ? tk : 0;
     e->topk = (fused_env && fused_env[0] == '0') ? 0 : e->topk_able;
   }
@@ -659,7 +668,7 @@ int icap_engine_set_fused_vocab(icap_engine* e, int on) {
   if (on && !e->topk_able)
     return fail(ICAP_ERR_UNSUPPORTED,
                 "icap_engine_set_fused_vocab: this engine's shape or precision is not served by "
-                "the fused projection (beam width <= 5, fp32, vocab %% 4 == 0, H %% 32 == 0)");
+                "the fused projection (beam width <= 5; fp32: vocab %% 4 == 0, H %% 32 == 0)");
   e->topk = on ? e->topk_able : 0;
   return ICAP_OK;
 }

@@ -13,6 +13,7 @@
 // rows are 144 bytes (128 of data + 16 pad) so that the 16-byte operand reads of 8
 // consecutive lanes fall in 8 distinct bank groups.
 #include "icap_common.h"
+#include "topk_epilogue.h"
 
 namespace icap {
 namespace {
@@ -41,9 +42,13 @@ struct Bf16Args {
   const float* emb_proj;  // [V,4H] token-only gate pre-activations, may be null
   const int32_t* ids;
   int H, V;
+  // top-k epilogue (dense_topk_bf16): per (row, 64 columns) records instead of y
+  float* rec;
+  float* eos_x;
+  int eos;
 };
 
-template <int BM, bool LSTM>
+template <int BM, bool LSTM, int TOPK = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   constexpr int NT = 256;
   constexpr int WTM = BM / 2;    // wave tile rows
@@ -53,7 +58,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   constexpr int B_LD = BN * (BK / 8) / NT;  // 16-byte loads per thread per stage
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int Z_BYTES = LSTM ? BM * ZLD * 4 : 0;
+  constexpr int T_LD = 68;  // floats per row of a wave's transposition patch (top-k epilogue)
+  constexpr int Z_BYTES = LSTM ? BM * ZLD * 4 : (TOPK > 0 ? 4 * WTM * T_LD * 4 : 0);
+  static_assert(TOPK == 0 || (!LSTM && BM == 128), "the top-k epilogue is built for 128-row tiles");
   constexpr int SMEM = 2 * STAGE > Z_BYTES ? 2 * STAGE : Z_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -163,7 +170,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
 #undef ICAP_BF16_LOAD_EARLY
 #undef ICAP_BF16_STORE
 
-  if (!LSTM) {
+  if constexpr (TOPK > 0) {
+    // The logits never reach memory: every wave writes its 64 x 64 patch (+ bias, -inf
+    // beyond N) to LDS row-major (the staging buffers are idle after the last barrier),
+    // then lane r folds row r of the patch into the row's record for these 64 columns.
+    constexpr int RL = 2 + 2 * TOPK;
+    float* patch = reinterpret_cast<float*>(smem) + wave * WTM * T_LD;
+    const int colbase = n0 + wn * 64;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = colbase + j * 32 + l31;
+      const bool n_ok = n < p.N;
+      const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          patch[lr * T_LD + j * 32 + l31] = n_ok ? acc[i][j][r] + bv : -INFINITY;
+        }
+    }
+    __syncthreads();
+    float x[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(patch + lane * T_LD + 4 * q);
+      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    const int row = m0 + wm * WTM + lane;
+    const TopkRow<TOPK> rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
+    if (row < p.M) {
+      if (rec.has_eos) p.eos_x[row] = rec.eos_v;
+      topk_store<TOPK>(p.rec + ((size_t)row * (2 * p.tiles_n) + 2 * tile_n + wn) * RL, rec);
+    }
+  } else if (!LSTM) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * 64 + j * 32 + l31;
@@ -286,6 +326,34 @@ int dense_bf16(const float* x, const void* packed_w, const float* bias, float* y
   // small problems: 64-row tiles keep more compute units busy
   if ((long long)ceil_div(M, 128) * ceil_div(N, BN) >= 256) return launch<128, false>(a, s, "gemm_bf16_kernel<128>");
   return launch<64, false>(a, s, "gemm_bf16_kernel<64>");
+}
+
+bool dense_topk_bf16_supported(const float* x, int M, int K, int N, int top_k) {
+  return (top_k == 1 || top_k == 3 || top_k == 5) && M > 0 && K > 0 && N > 0 && K % BK == 0 &&
+         aligned16(x);
+}
+
+// icap_dense_topk_f32 with bf16 operands: same records (see include/icap.h), packed weights.
+int dense_topk_bf16(const float* x, const void* packed_w, const float* bias, int M, int K, int N,
+                    int eos, int top_k, float* records, float* eos_logit, hipStream_t s) {
+  ICAP_REQUIRE(x && packed_w && records && eos_logit, "dense_topk_bf16: null pointer");
+  ICAP_REQUIRE(dense_topk_bf16_supported(x, M, K, N, top_k),
+               "dense_topk_bf16: needs top_k in {1,3,5}, K %% 64 == 0 and a 16-byte aligned x "
+               "(M=%d K=%d N=%d top_k=%d)", M, K, N, top_k);
+  ICAP_REQUIRE(aligned16(packed_w) && aligned16(records), "dense_topk_bf16: unaligned buffer");
+  Bf16Args a = {};
+  a.a0 = x; a.a1 = nullptr; a.K0 = K; a.lda0 = K; a.lda1 = 0;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = nullptr; a.M = M; a.N = N; a.K = K; a.act = ICAP_ACT_NONE;
+  a.rec = records; a.eos_x = eos_logit; a.eos = eos;
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, BN);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1>), grid, block, 0, s, a);
+  else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5>), grid, block, 0, s, a);
+  ICAP_LAUNCH_CHECK("gemm_bf16_kernel<topk>");
+  return ICAP_OK;
 }
 
 int lstm_step_bf16(const float* ctx, const float* h, const float* c, const void* packed_w,

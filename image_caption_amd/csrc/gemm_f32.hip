@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "icap_common.h"
+#include "topk_epilogue.h"
 
 namespace icap {
 namespace {
@@ -209,8 +210,6 @@ __device__ __forceinline__ float half_sum(float v, int half) {
   const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
   return half ? hi : lo;
 }
-
-constexpr int TOPK_EMPTY = 0x7fffffff;
 
 // Fast path of dense_f32: K % 32 == 0, 16-byte aligned operands, element counts below
 // 2^31.  Out-of-range rows / columns of edge tiles are CLAMPED to valid ones instead of
@@ -418,78 +417,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       const float4 v = *reinterpret_cast<const float4*>(patch + lr * T_LD + part * 32 + 4 * q);
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
-    float tx[TOPK];
-    int tc[TOPK];
-#pragma unroll
-    for (int k = 0; k < TOPK; ++k) { tx[k] = -INFINITY; tc[k] = TOPK_EMPTY; }
-    float eos_v = 0.f;
-    bool has_eos = false;
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const float v = x[e];
-      const int c = cbase + e;
-      if (c == p.eos) { eos_v = v; has_eos = true; }
-      // insert (v, c) into the descending list; strict '>' keeps the lower column on ties
-      bool gt[TOPK];
-#pragma unroll
-      for (int k = 0; k < TOPK; ++k) gt[k] = v > tx[k];
-#pragma unroll
-      for (int k = TOPK - 1; k >= 1; --k) {
-        tx[k] = gt[k - 1] ? tx[k - 1] : (gt[k] ? v : tx[k]);
-        tc[k] = gt[k - 1] ? tc[k - 1] : (gt[k] ? c : tc[k]);
-      }
-      tx[0] = gt[0] ? v : tx[0];
-      tc[0] = gt[0] ? c : tc[0];
-    }
-    float m = tx[0];
-    const float ms = (m > -INFINITY) ? m : 0.f;
-    float sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 32; e += 4)
-      sum += (fast_exp(x[e] - ms) + fast_exp(x[e + 1] - ms)) + (fast_exp(x[e + 2] - ms) + fast_exp(x[e + 3] - ms));
+    TopkRow<TOPK> rec = topk_scan<TOPK, 32>(x, cbase, p.eos);
+    if (rec.has_eos && row < p.M) p.eos_x[row] = rec.eos_v;
     // 3. the two lanes of a row meet (neighbour swap inside each quad)
-    constexpr int SWAP = 0xB1;  // quad_perm [1,0,3,2]
-    const float om = dpp_f<SWAP, 0xf>(0.f, m);
-    const float osum = dpp_f<SWAP, 0xf>(0.f, sum);
-    float ox[TOPK];
-    int oc[TOPK];
-#pragma unroll
-    for (int k = 0; k < TOPK; ++k) {
-      ox[k] = dpp_f<SWAP, 0xf>(0.f, tx[k]);
-      oc[k] = dpp_i<SWAP, 0xf>(0, tc[k]);
-    }
-    if (has_eos && row < p.M) p.eos_x[row] = eos_v;
-    if (part == 0 && row < p.M) {
-      // this lane's columns are the lower ones: on equal values its entries come first
-      const float M2 = fmaxf(m, om);
-      const float M2s = (M2 > -INFINITY) ? M2 : 0.f;
-      const float S2 = ((m > -INFINITY) ? sum * fast_exp(m - M2s) : 0.f) +
-                       ((om > -INFINITY) ? osum * fast_exp(om - M2s) : 0.f);
-      float out[RL];
-      out[0] = M2;
-      out[1] = S2;
-      // merge two descending lists (static indices only: each output picks by counting)
-      int ia = 0, ib = 0;
-#pragma unroll
-      for (int k = 0; k < TOPK; ++k) {
-        float av = -INFINITY, bvv = -INFINITY;
-        int ac = TOPK_EMPTY, bc = TOPK_EMPTY;
-#pragma unroll
-        for (int q = 0; q < TOPK; ++q) {
-          if (q == ia) { av = tx[q]; ac = tc[q]; }
-          if (q == ib) { bvv = ox[q]; bc = oc[q]; }
-        }
-        const bool take_a = (ac != TOPK_EMPTY) && (bc == TOPK_EMPTY || av >= bvv);
-        out[2 + k] = take_a ? av : bvv;
-        out[2 + TOPK + k] = __int_as_float(take_a ? ac : bc);
-        ia += take_a ? 1 : 0;
-        ib += take_a ? 0 : 1;
-      }
-      float4* dst = reinterpret_cast<float4*>(p.rec + ((size_t)row * n_ht + ht) * RL);
-#pragma unroll
-      for (int q = 0; q < RL / 4; ++q)
-        dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
-    }
+    rec = topk_merge_neighbour<TOPK>(rec);
+    if (part == 0 && row < p.M) topk_store<TOPK>(p.rec + ((size_t)row * n_ht + ht) * RL, rec);
   }
 }
 

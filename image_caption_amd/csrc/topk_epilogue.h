@@ -1,0 +1,121 @@
+// Per-row reduction used by the fused "projection + beam step" epilogues: a lane that holds
+// NX consecutive logits of one row folds them into the row's record for those columns -
+// maximum, sum of exp(x - max) and the TOPK largest values with their columns (equal
+// values: lower column first).  Records are 2 + 2*TOPK floats:
+//   [max, sum, x_0 .. x_{TOPK-1}, col_0 .. col_{TOPK-1} (int bits, TOPK_EMPTY = none)].
+#pragma once
+
+#include "icap_common.h"
+
+namespace icap {
+
+constexpr int TOPK_EMPTY = 0x7fffffff;
+
+#if defined(__HIPCC__)
+template <int TOPK>
+struct TopkRow {
+  float m;          // maximum (= x[0] of the list, -inf if no valid column)
+  float sum;        // sum exp(x - m)
+  float tx[TOPK];   // descending
+  int tc[TOPK];
+  float eos_v;      // the logit of column `eos` if it is among the scanned columns
+  bool has_eos;
+};
+
+// x[e] is the logit of column cbase + e; invalid columns must hold -inf.
+template <int TOPK, int NX>
+__device__ __forceinline__ TopkRow<TOPK> topk_scan(const float (&x)[NX], int cbase, int eos) {
+  TopkRow<TOPK> r;
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) { r.tx[k] = -INFINITY; r.tc[k] = TOPK_EMPTY; }
+  r.eos_v = 0.f;
+  r.has_eos = false;
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    const float v = x[e];
+    const int c = cbase + e;
+    if (c == eos) { r.eos_v = v; r.has_eos = true; }
+    // insert (v, c) into the descending list; strict '>' keeps the lower column on ties
+    bool gt[TOPK];
+#pragma unroll
+    for (int k = 0; k < TOPK; ++k) gt[k] = v > r.tx[k];
+#pragma unroll
+    for (int k = TOPK - 1; k >= 1; --k) {
+      r.tx[k] = gt[k - 1] ? r.tx[k - 1] : (gt[k] ? v : r.tx[k]);
+      r.tc[k] = gt[k - 1] ? r.tc[k - 1] : (gt[k] ? c : r.tc[k]);
+    }
+    r.tx[0] = gt[0] ? v : r.tx[0];
+    r.tc[0] = gt[0] ? c : r.tc[0];
+  }
+  r.m = r.tx[0];
+  const float ms = (r.m > -INFINITY) ? r.m : 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < NX; e += 4)
+    sum += (fast_exp(x[e] - ms) + fast_exp(x[e + 1] - ms)) +
+           (fast_exp(x[e + 2] - ms) + fast_exp(x[e + 3] - ms));
+  r.sum = sum;
+  return r;
+}
+
+// Merges the record of the neighbouring lane (lane ^ 1, which holds the HIGHER columns when
+// this lane is even) into this one; meaningful on even lanes.
+template <int TOPK>
+__device__ __forceinline__ TopkRow<TOPK> topk_merge_neighbour(const TopkRow<TOPK>& a) {
+  constexpr int SWAP = 0xB1;  // quad_perm [1,0,3,2]
+  const float om = dpp_f<SWAP, 0xf>(0.f, a.m);
+  const float osum = dpp_f<SWAP, 0xf>(0.f, a.sum);
+  float ox[TOPK];
+  int oc[TOPK];
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    ox[k] = dpp_f<SWAP, 0xf>(0.f, a.tx[k]);
+    oc[k] = dpp_i<SWAP, 0xf>(0, a.tc[k]);
+  }
+  TopkRow<TOPK> r;
+  r.eos_v = a.eos_v;
+  r.has_eos = a.has_eos;
+  r.m = fmaxf(a.m, om);
+  const float ms = (r.m > -INFINITY) ? r.m : 0.f;
+  r.sum = ((a.m > -INFINITY) ? a.sum * fast_exp(a.m - ms) : 0.f) +
+          ((om > -INFINITY) ? osum * fast_exp(om - ms) : 0.f);
+  // merge two descending lists (static indices only: each output picks by counting);
+  // this lane's columns are the lower ones, so on equal values its entries come first
+  int ia = 0, ib = 0;
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    float av = -INFINITY, bv = -INFINITY;
+    int ac = TOPK_EMPTY, bc = TOPK_EMPTY;
+#pragma unroll
+    for (int q = 0; q < TOPK; ++q) {
+      if (q == ia) { av = a.tx[q]; ac = a.tc[q]; }
+      if (q == ib) { bv = ox[q]; bc = oc[q]; }
+    }
+    const bool take_a = (ac != TOPK_EMPTY) && (bc == TOPK_EMPTY || av >= bv);
+    r.tx[k] = take_a ? av : bv;
+    r.tc[k] = take_a ? ac : bc;
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+  }
+  return r;
+}
+
+template <int TOPK>
+__device__ __forceinline__ void topk_store(float* dst, const TopkRow<TOPK>& r) {
+  constexpr int RL = 2 + 2 * TOPK;
+  float out[RL];
+  out[0] = r.m;
+  out[1] = r.sum;
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    out[2 + k] = r.tx[k];
+    out[2 + TOPK + k] = __int_as_float(r.tc[k]);
+  }
+  float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int q = 0; q < RL / 4; ++q)
+    d4[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+#endif
+
+}  // namespace icap

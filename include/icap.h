@@ -320,8 +320,9 @@ int icap_engine_set_timing(icap_engine* engine, unsigned class_mask);
  * recurrent_example.py:517-558). */
 int icap_engine_set_overlap(icap_engine* engine, int on);
 /* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
- * icap_beam_step_from_records_f32) whenever its shape is served: fp32, beam width <= 5,
- * V % 4 == 0, H % 32 == 0.  on == 0 selects the unfused kernels (a [B*W,V] logits buffer,
+ * icap_beam_step_from_records_f32; in bf16 mode the bf16 projection writes the same
+ * records) whenever its shape is served: beam width <= 5 and, for fp32, V % 4 == 0,
+ * H % 32 == 0.  on == 0 selects the unfused kernels (a [B*W,V] logits buffer,
  * icap_dense_f32 + icap_beam_step_f32); on != 0 returns ICAP_ERR_UNSUPPORTED for a shape
  * that is not served.  icap_engine_fused_vocab reports the current choice.  No
  * counterpart in the reference. */

@@ -152,3 +152,26 @@ def test_engine_bf16_rejects_unaligned_dims():
                         precision="bf16")
     with pytest.raises(RuntimeError, match="multiples of 64"):
         CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+
+
+def test_engine_bf16_fused_and_unfused_vocab_paths_agree():
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = co.perturb_biases(co.make_params(11, 128, 64, 64, 64, 1000), 12)
+    img = to_dev(co.make_images(13, 10, 16, 128))
+    cfg = CaptionConfig(B=10, W=5, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=8, start_id=3,
+                        eos_id=4, precision="bf16")
+    eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+    assert eng.fused_vocab
+    outs = []
+    for on in (True, False):
+        eng.set_fused_vocab(on)
+        tok, best = eng.decode(img)
+        tr = eng.trace()
+        outs.append((np_of(tok).copy(), np_of(best).copy(), np_of(tr["ids"]).copy(),
+                     np_of(tr["parents"]).copy(), np_of(tr["scores"]).copy()))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        if a.dtype == np.float32:
+            np.testing.assert_allclose(a, b, rtol=3e-6)
+        else:
+            np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(np.maximum(outs[0][4], -1e30), np.maximum(outs[1][4], -1e30), rtol=3e-6)
