@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libicap.so")
 ICAP_OK = 0
 ACT_NONE, ACT_RELU = 0, 1
 TILE_REFERENCE, TILE_REPEAT = 0, 1
-PRECISION_FP32, PRECISION_BF16 = 0, 1
+PRECISION_FP32, PRECISION_BF16, PRECISION_F32_SPLIT = 0, 1, 2
 MAX_BEAM_WIDTH = 16
 K_NAMES = ("encode", "feat_proj", "init_state", "attn_query", "attention", "lstm", "fc1",
            "vocab", "beam", "backtrack")
@@ -67,6 +67,11 @@ SIGNATURES = {
     "icap_pack_weight_bf16": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_dense_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "icap_lstm_step_bf16": ([_P] * 9 + [_I, _I, _I, _I, _P], C.c_int),
+    "icap_packed_split_bytes": ([_I, _I], C.c_size_t),
+    "icap_pack_weight_split": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_dense_split": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "icap_dense_topk_split": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "icap_lstm_step_split": ([_P] * 9 + [_I, _I, _I, _I, _P], C.c_int),
     "icap_dense_topk_half_tiles": ([_I], C.c_int),
     "icap_dense_topk_record_floats": ([_I], C.c_int),
     "icap_dense_topk_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),

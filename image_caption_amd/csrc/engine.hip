@@ -26,7 +26,7 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// kernels (gemm_f32.hip, gemm_bf16.hip, attention.hip, beam.hip, beam_unfused.hip)
+// kernels (gemm_f32.hip, gemm_bf16.hip, gemm_split.hip, attention.hip, beam.hip, beam_unfused.hip)
 int dense_f32(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int lstm_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
                   const float*, const float*, const float*, const float*, const float*, float*,
@@ -42,6 +42,14 @@ bool dense_topk_supported(const float*, const float*, int, int, int, int);
 int dense_topk_f32(const float*, const float*, const float*, int, int, int, int, int, float*, float*,
                    hipStream_t);
 bool beam_records_supported(int W, int half_tiles, int top_k);
+size_t packed_split_bytes(int K, int N);
+int pack_weight_split(const float*, void*, int, int, int, int, int, hipStream_t);
+int dense_split(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
+bool dense_topk_split_supported(const float*, int, int, int, int);
+int dense_topk_split(const float*, const void*, const float*, int, int, int, int, int, float*,
+                     float*, hipStream_t);
+int lstm_step_split(const float*, const float*, const float*, const void*, const float*,
+                    const float*, const int32_t*, float*, float*, int, int, int, int, hipStream_t);
 bool dense_topk_bf16_supported(const float*, int, int, int, int);
 int dense_topk_bf16(const float*, const void*, const float*, int, int, int, int, int, float*, float*,
                     hipStream_t);
@@ -137,8 +145,13 @@ int check_config(const icap_config& c) {
   ICAP_REQUIRE(c.tile_mode == ICAP_TILE_REFERENCE || c.tile_mode == ICAP_TILE_REPEAT,
                "engine: unknown tile_mode %d", c.tile_mode);
   ICAP_REQUIRE(c.U % 4 == 0 && c.D % 4 == 0, "engine: U and D must be multiples of 4");
-  if (c.precision != ICAP_PRECISION_FP32 && c.precision != ICAP_PRECISION_BF16)
+  if (c.precision != ICAP_PRECISION_FP32 && c.precision != ICAP_PRECISION_BF16 &&
+      c.precision != ICAP_PRECISION_F32_SPLIT)
     return fail(ICAP_ERR_UNSUPPORTED, "engine: precision %d is not built", c.precision);
+  if (c.precision == ICAP_PRECISION_F32_SPLIT && (c.F % 32 || c.D % 32 || c.E % 32 || c.H % 32))
+    return fail(ICAP_ERR_UNSUPPORTED,
+                "engine: split mode needs F, D, E and H to be multiples of 32 (got %d %d %d %d)",
+                c.F, c.D, c.E, c.H);
   if (c.precision == ICAP_PRECISION_BF16 &&
       (c.F % 64 || c.D % 64 || c.E % 64 || c.H % 64))
     return fail(ICAP_ERR_UNSUPPORTED,
@@ -184,6 +197,10 @@ int engine_dense(const icap_engine* e, int which, const float* x, const float* w
                  float* y, int M, int K, int N, int act, hipStream_t s) {
   if (e->cfg.precision == ICAP_PRECISION_BF16)
     return dense_bf16(x, e->pk[which], bias, y, M, K, N, act, s);
+  // split mode pays on the large products; the small projections (a few hundred 64x64
+  // tiles) are latency-bound and stay on the exact-f32 kernels
+  if (e->cfg.precision == ICAP_PRECISION_F32_SPLIT && (long long)ceil_div(M, 128) * ceil_div(N, 128) >= 256)
+    return dense_split(x, e->pk[which], bias, y, M, K, N, act, s);
   return dense_f32(x, wf, bias, y, M, K, N, act, s);
 }
 
@@ -255,6 +272,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       if (c.precision == ICAP_PRECISION_BF16)
         ICAP_TRY(lstm_step_bf16(e->ctx, e->h[cur], e->c, e->pk[icap_engine::PK_LSTM], w.lstm_bias,
                                 e->emb_proj, ids, e->h[cur ^ 1], e->c, N, c.D, c.H, c.V, s));
+      else if (c.precision == ICAP_PRECISION_F32_SPLIT && N >= 4096)
+        // (below that the exact-f32 LSTM kernel, one workgroup per CU, is as fast)
+        ICAP_TRY(lstm_step_split(e->ctx, e->h[cur], e->c, e->pk[icap_engine::PK_LSTM], w.lstm_bias,
+                                 e->emb_proj, ids, e->h[cur ^ 1], e->c, N, c.D, c.H, c.V, s));
       else
         ICAP_TRY(lstm_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur], e->c,
                                w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->h[cur ^ 1],
@@ -280,6 +301,9 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         if (c.precision == ICAP_PRECISION_BF16)
           ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
                                    c.eos_id, e->topk, e->rec, e->eos_x, s));
+        else if (c.precision == ICAP_PRECISION_F32_SPLIT)
+          ICAP_TRY(dense_topk_split(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
+                                    c.eos_id, e->topk, e->rec, e->eos_x, s));
         else
           ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
                                   e->topk, e->rec, e->eos_x, s));
@@ -324,7 +348,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 103; }
+int icap_version(void) { return 104; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -358,6 +382,33 @@ int icap_lstm_step_bf16(const float* ctx, const float* h, const float* c, const 
                         float* c_out, int N, int C, int H, int V, icap_stream_t stream) {
   return lstm_step_bf16(ctx, h, c, packed_w, bias, emb_proj, ids, h_out, c_out, N, C, H, V,
                         (hipStream_t)stream);
+}
+
+size_t icap_packed_split_bytes(int K, int N) { return packed_split_bytes(K, N); }
+
+int icap_pack_weight_split(const float* w, void* packed, int K_src, int N, int k_offset,
+                           int K_total, int gate_units, icap_stream_t stream) {
+  return pack_weight_split(w, packed, K_src, N, k_offset, K_total, gate_units, (hipStream_t)stream);
+}
+
+int icap_dense_split(const float* x, const void* packed_w, const float* bias, float* y, int M,
+                     int K, int N, int act, icap_stream_t stream) {
+  return dense_split(x, packed_w, bias, y, M, K, N, act, (hipStream_t)stream);
+}
+
+int icap_dense_topk_split(const float* x, const void* packed_w, const float* bias, int M, int K,
+                          int N, int eos_token, int top_k, float* records, float* eos_logit,
+                          icap_stream_t stream) {
+  return dense_topk_split(x, packed_w, bias, M, K, N, eos_token, top_k, records, eos_logit,
+                          (hipStream_t)stream);
+}
+
+int icap_lstm_step_split(const float* ctx, const float* h, const float* c, const void* packed_w,
+                         const float* bias, const float* emb_proj, const int32_t* ids,
+                         float* h_out, float* c_out, int N, int C, int H, int V,
+                         icap_stream_t stream) {
+  return lstm_step_split(ctx, h, c, packed_w, bias, emb_proj, ids, h_out, c_out, N, C, H, V,
+                         (hipStream_t)stream);
 }
 
 int icap_pool_features_f32(const float* features, const float* mask, float* pooled, int G, int L,
@@ -508,6 +559,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const bool gemm_ok =
         c.precision == ICAP_PRECISION_BF16
             ? dense_topk_bf16_supported(weights->fc2_kernel, (int)N, c.H, c.V, tk)
+        : c.precision == ICAP_PRECISION_F32_SPLIT
+            ? dense_topk_split_supported(weights->fc2_kernel, (int)N, c.H, c.V, tk)
             : dense_topk_supported(weights->fc2_kernel, weights->fc2_kernel, (int)N, c.H, c.V, tk);
     const bool shape_ok =
         c.W <= 5 && gemm_ok && beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
@@ -522,6 +575,9 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   if (c.precision == ICAP_PRECISION_BF16)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i)
       o_pk[i] = cv.take<char>(packed_weight_bytes(pk_dims[i][0], pk_dims[i][1]));
+  if (c.precision == ICAP_PRECISION_F32_SPLIT)
+    for (int i = 0; i < icap_engine::PK_COUNT; ++i)
+      o_pk[i] = cv.take<char>(packed_split_bytes(pk_dims[i][0], pk_dims[i][1]));
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
@@ -576,7 +632,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->emb_proj = (float*)(b + o_ep);
   e->rec = (float*)(b + o_rec);
   e->eos_x = (float*)(b + o_eosx);
-  if (c.precision == ICAP_PRECISION_BF16)
+  if (c.precision != ICAP_PRECISION_FP32)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i) e->pk[i] = b + o_pk[i];
   {
     const int rc = icap_engine_refresh_weights(e, nullptr);
@@ -600,20 +656,20 @@ int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
   const icap_weights& w = e->w;
   hipStream_t s = (hipStream_t)stream;
   const float* emb_rows = w.lstm_kernel + (size_t)c.D * 4 * c.H;  // kernel rows of the embedding
-  if (c.precision == ICAP_PRECISION_BF16) {
+  if (c.precision != ICAP_PRECISION_FP32) {
     typedef icap_engine E;
-    ICAP_TRY(pack_weight_bf16(w.enc_kernel, e->pk[E::PK_ENC], c.F, c.D, 0, c.F, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.att_w1_kernel, e->pk[E::PK_W1], c.D, c.U, 0, c.D, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.init_h_kernel, e->pk[E::PK_INIT_H], c.D, c.H, 0, c.D, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.init_c_kernel, e->pk[E::PK_INIT_C], c.D, c.H, 0, c.D, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.att_w2_kernel, e->pk[E::PK_W2], c.H, c.U, 0, c.H, 0, s));
+    auto pack = c.precision == ICAP_PRECISION_BF16 ? pack_weight_bf16 : pack_weight_split;
+    ICAP_TRY(pack(w.enc_kernel, e->pk[E::PK_ENC], c.F, c.D, 0, c.F, 0, s));
+    ICAP_TRY(pack(w.att_w1_kernel, e->pk[E::PK_W1], c.D, c.U, 0, c.D, 0, s));
+    ICAP_TRY(pack(w.init_h_kernel, e->pk[E::PK_INIT_H], c.D, c.H, 0, c.D, 0, s));
+    ICAP_TRY(pack(w.init_c_kernel, e->pk[E::PK_INIT_C], c.D, c.H, 0, c.D, 0, s));
+    ICAP_TRY(pack(w.att_w2_kernel, e->pk[E::PK_W2], c.H, c.U, 0, c.H, 0, s));
     // gate product over [ctx | h]: kernel rows [0,D) then the recurrent kernel, gates interleaved
-    ICAP_TRY(pack_weight_bf16(w.lstm_kernel, e->pk[E::PK_LSTM], c.D, 4 * c.H, 0, c.D + c.H, c.H, s));
-    ICAP_TRY(pack_weight_bf16(w.lstm_recurrent_kernel, e->pk[E::PK_LSTM], c.H, 4 * c.H, c.D,
-                              c.D + c.H, c.H, s));
-    ICAP_TRY(pack_weight_bf16(emb_rows, e->pk[E::PK_LSTM_EMB], c.E, 4 * c.H, 0, c.E, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.fc1_kernel, e->pk[E::PK_FC1], c.H, c.H, 0, c.H, 0, s));
-    ICAP_TRY(pack_weight_bf16(w.fc2_kernel, e->pk[E::PK_FC2], c.H, c.V, 0, c.H, 0, s));
+    ICAP_TRY(pack(w.lstm_kernel, e->pk[E::PK_LSTM], c.D, 4 * c.H, 0, c.D + c.H, c.H, s));
+    ICAP_TRY(pack(w.lstm_recurrent_kernel, e->pk[E::PK_LSTM], c.H, 4 * c.H, c.D, c.D + c.H, c.H, s));
+    ICAP_TRY(pack(emb_rows, e->pk[E::PK_LSTM_EMB], c.E, 4 * c.H, 0, c.E, 0, s));
+    ICAP_TRY(pack(w.fc1_kernel, e->pk[E::PK_FC1], c.H, c.H, 0, c.H, 0, s));
+    ICAP_TRY(pack(w.fc2_kernel, e->pk[E::PK_FC2], c.H, c.V, 0, c.H, 0, s));
   }
   // emb_proj[v] = embedding[v] . lstm_kernel[D:D+E]: the part of the LSTM gates that
   // depends only on the input token, hoisted out of the step loop

@@ -11,7 +11,8 @@ import torch
 from . import _lib, ops
 
 TILE_MODES = {"reference": _lib.TILE_REFERENCE, "repeat": _lib.TILE_REPEAT}
-PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}
+PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16,
+              "fp32_split": _lib.PRECISION_F32_SPLIT}
 
 # checkpoint (.npz) parameter name -> icap_weights field
 PARAM_TO_FIELD = {
@@ -61,7 +62,7 @@ class CaptionEngine:
         if config.tile_mode not in TILE_MODES:
             raise ValueError("tile_mode must be 'reference' or 'repeat'")
         if config.precision not in PRECISIONS:
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+            raise ValueError("precision must be 'fp32', 'fp32_split' or 'bf16'")
         self.config = config
         self.device = torch.device(device) if device is not None else \
             torch.device("cuda", torch.cuda.current_device())

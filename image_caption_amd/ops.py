@@ -330,3 +330,70 @@ def beam_step_from_records(rec, eos_logit, log_probs, finished, lengths, time, e
               parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(), B, W, int(V),
               current_stream())
     return scores, ids, parents, nlp, nfin, nlen
+
+
+# ---- split mode: fp32-accurate products on the bf16 matrix pipe -----------------------
+
+class PackedSplitWeight:
+    """A weight matrix split into three bf16 planes (hi + mid + lo == the fp32 value) and
+    packed [3, N_pad, K] for the split-mode kernels."""
+
+    def __init__(self, K, N, device, gate_units=0):
+        self.K, self.N, self.gate_units = int(K), int(N), int(gate_units)
+        nbytes = int(_lib.load().icap_packed_split_bytes(self.K, self.N))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def fill(self, kernel, k_offset=0):
+        K_src, N = kernel.shape
+        if N != self.N:
+            raise ValueError("PackedSplitWeight.fill: kernel has %d columns, expected %d" % (N, self.N))
+        _lib.call("icap_pack_weight_split", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
+                  K_src, N, int(k_offset), self.K, self.gate_units, current_stream())
+        return self
+
+
+def pack_weight_split(kernel, gate_units=0):
+    return PackedSplitWeight(kernel.shape[0], kernel.shape[1], kernel.device, gate_units).fill(kernel)
+
+
+def dense_split(x, packed, bias=None, act=ACT_NONE):
+    """act(x . W + bias) with fp32-accurate products on the bf16 matrix pipe; K % 32 == 0."""
+    if x.shape[-1] != packed.K:
+        raise ValueError("dense_split: input last dim %d != packed K %d" % (x.shape[-1], packed.K))
+    M = x.numel() // packed.K
+    out = torch.empty(*x.shape[:-1], packed.N, dtype=f32, device=x.device)
+    if M:
+        _lib.call("icap_dense_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+                  out.data_ptr(), M, packed.K, packed.N, act, current_stream())
+    return out
+
+
+def dense_topk_split(x, packed, bias, eos_token, top_k):
+    """dense_topk with the split-mode product; same records."""
+    M = x.numel() // packed.K
+    lib = _lib.load()
+    ht, rl = int(lib.icap_dense_topk_half_tiles(packed.N)), int(lib.icap_dense_topk_record_floats(top_k))
+    if rl == 0:
+        raise ValueError("dense_topk_split: top_k must be 1, 3 or 5")
+    rec = torch.empty(M, ht, rl, dtype=f32, device=x.device)
+    eos_logit = torch.zeros(M, dtype=f32, device=x.device)
+    _lib.call("icap_dense_topk_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+              M, packed.K, packed.N, int(eos_token), int(top_k), rec.data_ptr(), eos_logit.data_ptr(),
+              current_stream())
+    return rec, eos_logit
+
+
+def lstm_step_split(ctx, h, c, packed, bias, emb_proj=None, ids=None):
+    """One LSTM cell step on [ctx | h] in split mode; `packed` = PackedSplitWeight(C + H, 4H,
+    gate_units=H) filled with kernel[0:C] at 0 and the recurrent kernel at C."""
+    N, C = ctx.shape
+    H = h.shape[-1]
+    if packed.K != C + H or packed.N != 4 * H or packed.gate_units != H:
+        raise ValueError("lstm_step_split: packed weight does not match C=%d H=%d" % (C, H))
+    h_out = torch.empty_like(h)
+    c_out = torch.empty_like(c)
+    V = emb_proj.shape[0] if emb_proj is not None else 0
+    _lib.call("icap_lstm_step_split", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
+              packed.buf.data_ptr(), _opt(bias, f32, "bias"), _opt(emb_proj, f32, "emb_proj"),
+              _opt(ids, i32, "ids"), h_out.data_ptr(), c_out.data_ptr(), N, C, H, V, current_stream())
+    return h_out, c_out

@@ -40,6 +40,9 @@ extern "C" {
 #define ICAP_TILE_REPEAT 1    /* row r uses image r / W  (self-consistent layout) */
 
 #define ICAP_PRECISION_FP32 0 /* exact-f32 MFMA everywhere */
+#define ICAP_PRECISION_F32_SPLIT 2 /* fp32-accurate products on the bf16 matrix pipe: every fp32
+                                    * operand split exactly into three bf16 pieces, the six
+                                    * partial products of weight >= 2^-16 summed in fp32 */
 #define ICAP_PRECISION_BF16 1 /* bf16 operands on MFMA for every dense contraction, f32 accumulate */
 
 #define ICAP_MAX_BEAM_WIDTH 16
@@ -137,6 +140,27 @@ int icap_lstm_step_bf16(const float* ctx, const float* h, const float* c,
                         const void* packed_w, const float* bias, const float* emb_proj,
                         const int32_t* ids, float* h_out, float* c_out,
                         int N, int C, int H, int V, icap_stream_t stream);
+
+/* ---- split mode (ICAP_PRECISION_F32_SPLIT) -----------------------------------------
+ * Same contractions with fp32 accuracy at 6/16 of the exact-f32 matrix-pipe time: an fp32
+ * number is exactly hi + mid + lo with three bf16 pieces, the product of two bf16 numbers is
+ * exact in fp32, and hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid differs from a*b by
+ * at most 2^-23 |a*b| (the dropped pieces have weight 2^-24 and 2^-32).  Sums are fp32.
+ * Weights are split once into three planes, each packed like icap_pack_weight_bf16 packs
+ * its one: [3][N_pad][K_total] bf16; arguments as for the bf16 entry points, K % 32 == 0.
+ * icap_dense_topk_split writes the records of icap_dense_topk_f32. */
+size_t icap_packed_split_bytes(int K, int N);
+int icap_pack_weight_split(const float* w, void* packed, int K_src, int N, int k_offset,
+                           int K_total, int gate_units, icap_stream_t stream);
+int icap_dense_split(const float* x, const void* packed_w, const float* bias, float* y,
+                     int M, int K, int N, int act, icap_stream_t stream);
+int icap_dense_topk_split(const float* x, const void* packed_w, const float* bias, int M,
+                          int K, int N, int eos_token, int top_k, float* records,
+                          float* eos_logit, icap_stream_t stream);
+int icap_lstm_step_split(const float* ctx, const float* h, const float* c,
+                         const void* packed_w, const float* bias, const float* emb_proj,
+                         const int32_t* ids, float* h_out, float* c_out,
+                         int N, int C, int H, int V, icap_stream_t stream);
 
 /* Fused beam-search step for B images x W beams x V words: log-softmax, finished
  * masking, accumulated log-prob, length penalty, top-W over the flattened W*V

@@ -77,6 +77,17 @@ def main():
         run(name, lambda: ops.dense_bf16(x, pw, b, act=act), flops=2.0 * M * K * Nn,
             bytes_=K * Nn * 2.0 + M * K * 4.0 + M * Nn * 4.0)
 
+    # split mode (fp32-accurate products on the bf16 pipe)
+    for name, (M, K, Nn, act) in {
+            "split encode": (B * L, F, D, 1), "split fc1": (N, H, H, 0), "split vocab": (N, H, V, 0)}.items():
+        x, w, b = rn(M, K), rn(K, Nn) * 0.05, rn(Nn)
+        pw = ops.pack_weight_split(w)
+        run(name, lambda: ops.dense_split(x, pw, b, act=act), flops=2.0 * M * K * Nn)
+    x, w, b = rn(N, H), rn(H, V) * 0.05, rn(V)
+    pw = ops.pack_weight_split(w)
+    run("split topk vocab", lambda: ops.dense_topk_split(x, pw, b, 4, 1 if W == 1 else (3 if W <= 3 else 5)),
+        flops=2.0 * N * H * V)
+
     # lstm
     ctx, h, c = rn(N, D), rn(N, H) * 0.3, rn(N, H) * 0.3
     kern, rec, bias = rn(D + E, 4 * H) * 0.05, rn(H, 4 * H) * 0.05, rn(4 * H) * 0.1
@@ -90,6 +101,10 @@ def main():
         flops=2.0 * N * (D + H) * 4 * H)
     pk = ops.PackedWeight(D + H, 4 * H, dev, gate_units=H).fill(kern[:D].contiguous(), 0).fill(rec, D)
     run("bf16 lstm_step", lambda: ops.lstm_step_bf16(ctx, h, c, pk, bias, emb_proj, ids),
+        flops=2.0 * N * (D + H) * 4 * H)
+
+    pks = ops.PackedSplitWeight(D + H, 4 * H, dev, gate_units=H).fill(kern[:D].contiguous(), 0).fill(rec, D)
+    run("split lstm_step", lambda: ops.lstm_step_split(ctx, h, c, pks, bias, emb_proj, ids),
         flops=2.0 * N * (D + H) * 4 * H)
 
     # attention
