@@ -92,24 +92,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     _Pragma("unroll") for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const uint4*>(      \
         p.w + (size_t)(n0 + b_r + 32 * j) * p.K + k0_ + b_ch * 8);                                 \
   }
-  // in-loop form: issued through inline asm so that the prefetch stays at the top of the
-  // stage (plain loads are sunk to just above their use); waited for explicitly
-#define ICAP_BF16_LOAD_EARLY(KT)                                                                   \
-  {                                                                                                \
-    const int k0_ = (KT) * BK;                                                                     \
-    const bool seg0_ = k0_ < p.K0;                                                                 \
-    const float* base_ = seg0_ ? p.a0 : p.a1;                                                      \
-    const int ld_ = seg0_ ? p.lda0 : p.lda1;                                                       \
-    const int kk_ = (seg0_ ? k0_ : k0_ - p.K0) + a_c4 * 4;                                         \
-    _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                               \
-        asm volatile("global_load_dwordx4 %0, %1, off"                                             \
-                     : "=v"(ra[i])                                                                 \
-                     : "v"(base_ + (size_t)a_row[i] * ld_ + kk_));                                 \
-    _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                               \
-        asm volatile("global_load_dwordx4 %0, %1, off"                                             \
-                     : "=v"(rb[j])                                                                 \
-                     : "v"(p.w + (size_t)(n0 + b_r + 32 * j) * p.K + k0_ + b_ch * 8));             \
-  }
 #define ICAP_BF16_STORE(BUF)                                                                       \
   {                                                                                                \
     char* as_ = smem + (BUF) * STAGE;                                                              \
@@ -132,13 +114,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // One barrier per stage, below the next stage's loads: memory operations are not moved
+  // across a barrier, so the prefetch stays at the top of the stage, in flight during the
+  // multiplies; the staging registers then pass through an empty asm so that their first
+  // use (a register-only conversion) and its wait stay below the multiplies.
   const int nk = p.K / BK;
   ICAP_BF16_LOAD(0)
   ICAP_BF16_STORE(0)
-  __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    ICAP_BF16_LOAD_EARLY(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch
+    ICAP_BF16_LOAD(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch
+    __syncthreads();
     const char* as = smem + cur * STAGE + (wm * WTM + l31) * ROW_B + half * 16;
     const char* bs = smem + cur * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B + half * 16;
 #pragma unroll
@@ -154,20 +140,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    // the wait, then every staging register passes through an (empty) asm so that no use
-    // of it - not even a register-only conversion - can be scheduled above the wait
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) asm volatile("" : "+v"(rb[j].x), "+v"(rb[j].y), "+v"(rb[j].z), "+v"(rb[j].w));
     ICAP_BF16_STORE(cur ^ 1)
-    __syncthreads();
     cur ^= 1;
   }
+  __syncthreads();  // the epilogues reuse the LDS
 
 #undef ICAP_BF16_LOAD
-#undef ICAP_BF16_LOAD_EARLY
 #undef ICAP_BF16_STORE
 
   if constexpr (TOPK > 0) {

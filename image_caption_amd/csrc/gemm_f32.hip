@@ -322,21 +322,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       }
   };
 
-  // The prefetch of the next K step is issued through inline asm at the top of the step:
-  // written as plain loads, the scheduler sinks them to just above the LDS stores at the
-  // bottom (two MFMAs before their wait), which exposes the memory latency in every step.
-  // The compiler does not count these loads, so the wait before the stores is explicit.
-#define ICAP_LOAD_TILES_EARLY(a_tile_, b_tile_)                                                  \
-  _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                               \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"((a_tile_) + off_a[i])); \
-  _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                               \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"((b_tile_) + off_b[i]));
+  // One barrier per K step, placed BELOW the next step's loads: memory operations are not
+  // moved across a barrier, so the prefetch stays at the top of the step and is in flight
+  // during the multiplies (issued below the barrier, the scheduler sinks the loads to just
+  // above the LDS stores and every step waits out a memory latency).  Before the stores the
+  // staging registers pass through an empty asm, which keeps their first use - and the wait
+  // that goes with it - below the multiplies.
   const int nk = p.K / BK;
   const float* a_tile = p.A;
   const float* b_tile = p.B;
   ICAP_LOAD_TILES(a_tile, b_tile)
   ICAP_STORE_TILES(0)
-  __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
@@ -345,7 +341,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
     const bool more = t + 1 < nk;
     a_tile += more ? BK : 0;
     b_tile += more ? (size_t)BK * p.ldb : 0;
-    ICAP_LOAD_TILES_EARLY(a_tile, b_tile)
+    ICAP_LOAD_TILES(a_tile, b_tile)
+    __syncthreads();  // step t is in LDS; nobody reads buffer buf^1 any more
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float4 a[TM];
@@ -353,17 +350,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       read_frags(buf, g, a, b);
       mfma_group(a, b);
     }
-    // the wait, then every staging register passes through an (empty) asm so that no use
-    // of it can be scheduled above the wait
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
     ICAP_STORE_TILES(buf ^ 1)
-    __syncthreads();
   }
-#undef ICAP_LOAD_TILES_EARLY
+  __syncthreads();  // (the top-k epilogue reuses the LDS)
 
   if constexpr (TOPK == 0) {
 #pragma unroll
@@ -959,23 +952,6 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                  \
         *reinterpret_cast<const float4*>(a_ + (in_ctx_ ? off_a_ctx[i] : off_a_h[i]));         \
   }
-  // The in-loop prefetch goes through inline asm so that it stays at the top of the step
-  // (plain loads are sunk to just above the LDS stores, and with one workgroup per compute
-  // unit nothing else would cover that latency); its wait is explicit, before the stores.
-#define ICAP_LW_LOAD_EARLY(K0)                                                                \
-  {                                                                                           \
-    const int k0_ = (K0);                                                                     \
-    const bool in_ctx_ = k0_ < p.C;                                                           \
-    const float* b_ = in_ctx_ ? p.kernel + (size_t)k0_ * H4                                   \
-                              : p.recurrent + (size_t)(k0_ - p.C) * H4;                       \
-    const float* a_ = in_ctx_ ? p.ctx + k0_ : p.h + (k0_ - p.C);                              \
-    _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                          \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(b_ + off_b[i]));   \
-    _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                          \
-        asm volatile("global_load_dwordx4 %0, %1, off"                                        \
-                     : "=v"(ra[i])                                                            \
-                     : "v"(a_ + (in_ctx_ ? off_a_ctx[i] : off_a_h[i])));                      \
-  }
 #define ICAP_LW_STORE(BUF)                                                                    \
   {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < B_LD; ++i)                                          \
@@ -986,13 +962,16 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     }                                                                                         \
   }
 
+  // One barrier per K step, below the next step's loads (see dense_f32_fast_kernel): the
+  // prefetch stays in flight during the multiplies, which matters here because there is no
+  // second workgroup on the compute unit to cover a memory latency.
   const int nk = K / LBK;
   ICAP_LW_LOAD(0)
   ICAP_LW_STORE(0)
-  __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
-    ICAP_LW_LOAD_EARLY(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
+    ICAP_LW_LOAD(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
+    __syncthreads();
 #pragma unroll
     for (int g = 0; g < LBK / 8; ++g) {
       const float4 a = As[buf][2 * g + half][rg * 32 + l31];
@@ -1004,15 +983,13 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));  // uses stay below the wait
+    for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));  // uses stay below the multiplies
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
     ICAP_LW_STORE(buf ^ 1)
-    __syncthreads();
   }
-#undef ICAP_LW_LOAD_EARLY
+  __syncthreads();  // the gate exchange reuses the staging buffers
 #undef ICAP_LW_LOAD
 #undef ICAP_LW_STORE
 
