@@ -33,6 +33,9 @@ CONFIGS = {
     # BASELINE.json configs[2], per-GPU share (512 of the 4096 images), bf16 operands
     "beam5_b512_bf16": dict(B=512, W=5, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000, T=20,
                             precision="bf16"),
+    # the headline shape over the GRU sibling decoder (decoder/recurrent_decoder.py)
+    "beam3_b512_fp32_gru": dict(B=512, W=3, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000,
+                                T=20, precision="fp32", cell="gru"),
     "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
                              precision="fp32"),
 }
@@ -68,14 +71,17 @@ def cpu_baseline(cfg, budget_s=12.0):
     except Exception:
         threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     Bs = 32
+    cell = cfg.get("cell", "lstm")
     p = co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"])
+    if cell == "gru":
+        p = co.add_gru_params(p, 0)
     img = co.make_images(1, Bs, cfg["L"], cfg["F"])
-    co.predict_image_caption_sequence(p, img[:4], cfg["W"], 2, 3, 4)      # warm the BLAS pool
+    co.predict_image_caption_sequence(p, img[:4], cfg["W"], 2, 3, 4, cell=cell)  # warm the BLAS pool
     def rate(hoist, budget):
         reps, t0 = 0, time.perf_counter()
         while True:
             co.predict_image_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, 1.0, "reference",
-                                              hoist_w1=hoist)
+                                              hoist_w1=hoist, cell=cell)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget or reps >= 50:
@@ -121,6 +127,8 @@ def main():
     cfg = dict(CONFIGS[args.config])
     precision = cfg.pop("precision")
     p = synthetic.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"], cfg["U"])
+    if cfg.get("cell") == "gru":
+        p = synthetic.add_gru_params(p, 0)
     ccfg = CaptionConfig(start_id=3, eos_id=4, length_penalty_weight=1.0, tile_mode=args.tile_mode,
                          precision=precision, **cfg)
     eng = CaptionEngine(ccfg, p, device=device)

@@ -14,6 +14,7 @@ ICAP_OK = 0
 ACT_NONE, ACT_RELU = 0, 1
 TILE_REFERENCE, TILE_REPEAT = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F32_SPLIT = 0, 1, 2
+CELL_LSTM, CELL_GRU = 0, 1
 MAX_BEAM_WIDTH = 16
 K_NAMES = ("encode", "feat_proj", "init_state", "attn_query", "attention", "lstm", "fc1",
            "vocab", "beam", "backtrack")
@@ -32,7 +33,7 @@ class IcapConfig(C.Structure):
                                          "start_id", "eos_id", "tile_mode", "precision")] + [
         ("length_penalty_weight", C.c_double),
         ("reset_state_from_feat", C.c_float),
-        ("reserved", C.c_int32)]
+        ("cell", C.c_int32)]
 
 
 WEIGHT_FIELDS = ("enc_kernel", "enc_bias", "embedding", "init_h_kernel", "init_h_bias",
@@ -59,6 +60,8 @@ SIGNATURES = {
     "icap_attention_f32": ([_P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P,
                             _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_lstm_step_f32": ([_P] * 12 + [_I] * 5 + [_P], C.c_int),
+    "icap_gru_pack_f32": ([_P] * 6 + [_I] * 2 + [_P], C.c_int),
+    "icap_gru_step_f32": ([_P] * 10 + [_I] * 5 + [_P], C.c_int),
     "icap_beam_step_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                             _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),

@@ -31,6 +31,11 @@ int dense_f32(const float*, const float*, const float*, float*, int, int, int, i
 int lstm_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
                   const float*, const float*, const float*, const float*, const float*, float*,
                   float*, int, int, int, int, int, hipStream_t);
+int gru_pack_f32(const float*, const float*, const float*, float*, float*, float*, int, int,
+                 hipStream_t);
+int gru_step_f32(const float*, const float*, const float*, const int32_t*, const float*,
+                 const float*, const float*, const float*, const float*, float*, int, int, int, int,
+                 int, hipStream_t);
 size_t packed_weight_bytes(int K, int N);
 int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int dense_bf16(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
@@ -101,6 +106,10 @@ struct icap_engine {
   char* beam_ws;
   size_t beam_ws_bytes;
   float* emb_proj;  // [V,4H] = embedding . lstm_kernel[D:D+E]  (token-only part of the gates)
+  // GRU cell: the Keras variables re-laid as four pre-activation columns per unit
+  float *gru_k4 = nullptr, *gru_r4 = nullptr, *gru_b4 = nullptr;
+  // the gate operands the step kernels read (the caller's LSTM variables or the GRU re-layout)
+  const float *cell_kernel = nullptr, *cell_recurrent = nullptr, *cell_bias = nullptr;
   // bf16 mode: weights packed as bf16 [N_pad][K] (null in fp32 mode)
   enum { PK_ENC, PK_W1, PK_INIT_H, PK_INIT_C, PK_W2, PK_LSTM, PK_LSTM_EMB, PK_FC1, PK_FC2, PK_COUNT };
   void* pk[PK_COUNT] = {};
@@ -145,6 +154,9 @@ int check_config(const icap_config& c) {
   ICAP_REQUIRE(c.tile_mode == ICAP_TILE_REFERENCE || c.tile_mode == ICAP_TILE_REPEAT,
                "engine: unknown tile_mode %d", c.tile_mode);
   ICAP_REQUIRE(c.U % 4 == 0 && c.D % 4 == 0, "engine: U and D must be multiples of 4");
+  ICAP_REQUIRE(c.cell == ICAP_CELL_LSTM || c.cell == ICAP_CELL_GRU, "engine: unknown cell %d", c.cell);
+  if (c.cell == ICAP_CELL_GRU && c.precision == ICAP_PRECISION_BF16)
+    return fail(ICAP_ERR_UNSUPPORTED, "engine: the GRU cell is built for fp32 and fp32 split mode");
   if (c.precision != ICAP_PRECISION_FP32 && c.precision != ICAP_PRECISION_BF16 &&
       c.precision != ICAP_PRECISION_F32_SPLIT)
     return fail(ICAP_ERR_UNSUPPORTED, "engine: precision %d is not built", c.precision);
@@ -210,6 +222,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const icap_weights& w = e->w;
   const int N = c.B * c.W;
   const int BL = c.B * c.L;
+  const bool gru = c.cell == ICAP_CELL_GRU;
 
   {  // K0: features = relu(img . Wenc + benc)
     Timed t(e, ICAP_K_ENCODE, s);
@@ -226,12 +239,14 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     ICAP_TRY(pool_features_f32(e->features, nullptr, e->pooled, c.B, c.L, c.D, s));
     ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_H, e->pooled, w.init_h_kernel, w.init_h_bias,
                           e->init_h, c.B, c.D, c.H, ICAP_ACT_NONE, s));
-    ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_C, e->pooled, w.init_c_kernel, w.init_c_bias,
-                          e->init_c, c.B, c.D, c.H, ICAP_ACT_NONE, s));
     ICAP_TRY(expand_rows_f32(e->init_h, e->h[0], c.B, c.W, c.H, c.reset_state_from_feat,
                              c.tile_mode, s));
-    ICAP_TRY(expand_rows_f32(e->init_c, e->c, c.B, c.W, c.H, c.reset_state_from_feat, c.tile_mode,
-                             s));
+    if (!gru) {
+      ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_C, e->pooled, w.init_c_kernel, w.init_c_bias,
+                            e->init_c, c.B, c.D, c.H, ICAP_ACT_NONE, s));
+      ICAP_TRY(expand_rows_f32(e->init_c, e->c, c.B, c.W, c.H, c.reset_state_from_feat,
+                               c.tile_mode, s));
+    }
     hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, e->start_ids,
                        c.start_id, N);
     ICAP_LAUNCH_CHECK("fill_i32_kernel");
@@ -248,28 +263,34 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // projection / beam step of step t.  It runs on the side stream beside them:
   //   main: lstm_t -> fc1_t -> vocab_t -> beam_t -> lstm_{t+1} ...
   //   side:        \-> query_{t+1} -> attention_{t+1} -/
-  auto attention_step = [&](hipStream_t st) -> int {
-    {  // K4: q = W2(c) + b2      (the query is the LSTM cell state)
+  // state: the attention query and the beta gate read the LSTM cell state c
+  // (lstm_recurrent_decoder.py:80) or the GRU state h (recurrent_decoder.py:77,90)
+  auto attention_step = [&](hipStream_t st, const float* state) -> int {
+    {  // K4: q = W2(state) + b2
       Timed tm(e, ICAP_K_ATTN_QUERY, st);
-      ICAP_TRY(engine_dense(e, icap_engine::PK_W2, e->c, w.att_w2_kernel, w.att_w2_bias, e->q, N,
+      ICAP_TRY(engine_dense(e, icap_engine::PK_W2, state, w.att_w2_kernel, w.att_w2_bias, e->q, N,
                             c.H, c.U, ICAP_ACT_NONE, st));
     }
     {  // K5: additive attention + beta gate
       Timed tm(e, ICAP_K_ATTENTION, st);
       ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
-                             e->c, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
+                             state, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
                              stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st));
     }
     return ICAP_OK;
   };
-  ICAP_TRY(attention_step(s));
   int cur = 0;
+  ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
   for (int t = 0; t < c.T; ++t) {
     const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
     if (t > 0 && e->overlap) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
     {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
-      if (c.precision == ICAP_PRECISION_BF16)
+      if (gru)
+        ICAP_TRY(gru_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur],
+                              e->cell_kernel, e->cell_recurrent, e->cell_bias, e->h[cur ^ 1], N, c.D,
+                              c.E, c.H, c.V, s));
+      else if (c.precision == ICAP_PRECISION_BF16)
         ICAP_TRY(lstm_step_bf16(e->ctx, e->h[cur], e->c, e->pk[icap_engine::PK_LSTM], w.lstm_bias,
                                 e->emb_proj, ids, e->h[cur ^ 1], e->c, N, c.D, c.H, c.V, s));
       else if (c.precision == ICAP_PRECISION_F32_SPLIT && N >= 4096)
@@ -285,7 +306,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     if (t + 1 < c.T && e->overlap) {
       ICAP_HIP(hipEventRecord(e->ev_lstm, s));
       ICAP_HIP(hipStreamWaitEvent(e->side, e->ev_lstm, 0));
-      ICAP_TRY(attention_step(e->side));
+      ICAP_TRY(attention_step(e->side, gru ? e->h[cur] : e->c));
       ICAP_HIP(hipEventRecord(e->ev_att, e->side));
     }
     {  // K7: fc1
@@ -308,7 +329,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
                                   e->topk, e->rec, e->eos_x, s));
       }
-      if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s));
+      if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
       Timed tm(e, ICAP_K_BEAM, s);
       ICAP_TRY(beam_step_from_records_f32(
           e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, t, c.eos_id,
@@ -322,7 +343,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
                             c.H, c.V, ICAP_ACT_NONE, s));
     }
-    if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s));
+    if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
     {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
        // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
@@ -348,7 +369,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 104; }
+int icap_version(void) { return 105; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -444,6 +465,21 @@ int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table, c
                        c_out, N, C, E, H, V, (hipStream_t)stream);
 }
 
+int icap_gru_pack_f32(const float* kernel, const float* recurrent_kernel, const float* bias,
+                      float* kernel4, float* recurrent4, float* bias4, int CE, int H,
+                      icap_stream_t stream) {
+  return gru_pack_f32(kernel, recurrent_kernel, bias, kernel4, recurrent4, bias4, CE, H,
+                      (hipStream_t)stream);
+}
+
+int icap_gru_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
+                      const float* emb_proj, const float* h, const float* kernel4,
+                      const float* recurrent4, const float* bias4, float* h_out, int N, int C, int E,
+                      int H, int V, icap_stream_t stream) {
+  return gru_step_f32(ctx, emb, table, ids, emb_proj, h, kernel4, recurrent4, bias4, h_out, N, C, E,
+                      H, V, (hipStream_t)stream);
+}
+
 int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
                        const int32_t* lengths, int time, int start_offset, int eos_token,
                        double length_penalty_weight, int input_is_log_prob, float* scores,
@@ -526,8 +562,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   *out = nullptr;
   ICAP_TRY(check_config(*config));
   const void* const* wp = reinterpret_cast<const void* const*>(weights);
-  for (size_t i = 0; i < sizeof(icap_weights) / sizeof(void*); ++i)
-    ICAP_REQUIRE(wp[i] != nullptr, "icap_engine_create: weight pointer %zu is null", i);
+  for (size_t i = 0; i < sizeof(icap_weights) / sizeof(void*); ++i) {
+    const bool optional = config->cell == ICAP_CELL_GRU &&
+                          (&wp[i] == reinterpret_cast<const void* const*>(&weights->init_c_kernel) ||
+                           &wp[i] == reinterpret_cast<const void* const*>(&weights->init_c_bias));
+    ICAP_REQUIRE(optional || wp[i] != nullptr, "icap_engine_create: weight pointer %zu is null", i);
+  }
   icap_engine* e = new (std::nothrow) icap_engine();
   ICAP_REQUIRE(e, "icap_engine_create: out of host memory");
   e->cfg = *config;
@@ -547,6 +587,10 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
                o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
+  const bool gru = c.cell == ICAP_CELL_GRU;
+  const size_t o_gk = cv.take<float>(gru ? (size_t)(c.D + c.E) * 4 * c.H : 0),
+               o_gr = cv.take<float>(gru ? (size_t)c.H * 4 * c.H : 0),
+               o_gb = cv.take<float>(gru ? (size_t)4 * c.H : 0);
   // packed bf16 weights: {K, N} per matrix
   const int pk_dims[icap_engine::PK_COUNT][2] = {
       {c.F, c.D}, {c.D, c.U}, {c.D, c.H}, {c.D, c.H}, {c.H, c.U},
@@ -630,6 +674,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws = b + o_bws;
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
+  if (gru) {
+    e->gru_k4 = (float*)(b + o_gk);
+    e->gru_r4 = (float*)(b + o_gr);
+    e->gru_b4 = (float*)(b + o_gb);
+  }
+  e->cell_kernel = gru ? e->gru_k4 : weights->lstm_kernel;
+  e->cell_recurrent = gru ? e->gru_r4 : weights->lstm_recurrent_kernel;
+  e->cell_bias = gru ? e->gru_b4 : weights->lstm_bias;
   e->rec = (float*)(b + o_rec);
   e->eos_x = (float*)(b + o_eosx);
   if (c.precision != ICAP_PRECISION_FP32)
@@ -655,18 +707,22 @@ int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
   const icap_config& c = e->cfg;
   const icap_weights& w = e->w;
   hipStream_t s = (hipStream_t)stream;
-  const float* emb_rows = w.lstm_kernel + (size_t)c.D * 4 * c.H;  // kernel rows of the embedding
+  const bool gru = c.cell == ICAP_CELL_GRU;
+  if (gru)
+    ICAP_TRY(gru_pack_f32(w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->gru_k4, e->gru_r4,
+                          e->gru_b4, c.D + c.E, c.H, s));
+  const float* emb_rows = e->cell_kernel + (size_t)c.D * 4 * c.H;  // kernel rows of the embedding
   if (c.precision != ICAP_PRECISION_FP32) {
     typedef icap_engine E;
     auto pack = c.precision == ICAP_PRECISION_BF16 ? pack_weight_bf16 : pack_weight_split;
     ICAP_TRY(pack(w.enc_kernel, e->pk[E::PK_ENC], c.F, c.D, 0, c.F, 0, s));
     ICAP_TRY(pack(w.att_w1_kernel, e->pk[E::PK_W1], c.D, c.U, 0, c.D, 0, s));
     ICAP_TRY(pack(w.init_h_kernel, e->pk[E::PK_INIT_H], c.D, c.H, 0, c.D, 0, s));
-    ICAP_TRY(pack(w.init_c_kernel, e->pk[E::PK_INIT_C], c.D, c.H, 0, c.D, 0, s));
+    if (!gru) ICAP_TRY(pack(w.init_c_kernel, e->pk[E::PK_INIT_C], c.D, c.H, 0, c.D, 0, s));
     ICAP_TRY(pack(w.att_w2_kernel, e->pk[E::PK_W2], c.H, c.U, 0, c.H, 0, s));
     // gate product over [ctx | h]: kernel rows [0,D) then the recurrent kernel, gates interleaved
-    ICAP_TRY(pack(w.lstm_kernel, e->pk[E::PK_LSTM], c.D, 4 * c.H, 0, c.D + c.H, c.H, s));
-    ICAP_TRY(pack(w.lstm_recurrent_kernel, e->pk[E::PK_LSTM], c.H, 4 * c.H, c.D, c.D + c.H, c.H, s));
+    ICAP_TRY(pack(e->cell_kernel, e->pk[E::PK_LSTM], c.D, 4 * c.H, 0, c.D + c.H, c.H, s));
+    ICAP_TRY(pack(e->cell_recurrent, e->pk[E::PK_LSTM], c.H, 4 * c.H, c.D, c.D + c.H, c.H, s));
     ICAP_TRY(pack(emb_rows, e->pk[E::PK_LSTM_EMB], c.E, 4 * c.H, 0, c.E, 0, s));
     ICAP_TRY(pack(w.fc1_kernel, e->pk[E::PK_FC1], c.H, c.H, 0, c.H, 0, s));
     ICAP_TRY(pack(w.fc2_kernel, e->pk[E::PK_FC2], c.H, c.V, 0, c.H, 0, s));

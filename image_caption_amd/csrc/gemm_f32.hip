@@ -670,7 +670,33 @@ struct LstmArgs {
 constexpr int LSTM_BM = 32;
 constexpr int LSTM_BJ = 32;
 
-template <bool VEC>
+// CELL selects the cell update applied to the four pre-activation tiles of a unit:
+//   CELL_LSTM  i, f, g, o  (Keras LSTMCell)
+//   CELL_GRU   z, r, x_h, rec_h with the operands packed by gru_pack_f32 (Keras GRUCell,
+//              reset_after=True): h' = z*h + (1-z)*tanh(x_h + r*rec_h)
+constexpr int CELL_LSTM = 0;
+constexpr int CELL_GRU = 1;
+
+template <int CELL>
+__device__ __forceinline__ void cell_update(const LstmArgs& p, size_t o, float z0, float z1, float z2,
+                                            float z3) {
+  if (CELL == CELL_LSTM) {
+    const float ig = fast_sigmoid(z0);
+    const float fg = fast_sigmoid(z1);
+    const float gg = fast_tanh(z2);
+    const float og = fast_sigmoid(z3);
+    const float c_new = fg * p.c[o] + ig * gg;
+    p.c_out[o] = c_new;
+    p.h_out[o] = og * fast_tanh(c_new);
+  } else {
+    const float zg = fast_sigmoid(z0);
+    const float rg = fast_sigmoid(z1);
+    const float hh = fast_tanh(z2 + rg * z3);
+    p.h_out[o] = zg * p.h[o] + (1.f - zg) * hh;
+  }
+}
+
+template <bool VEC, int CELL>
 __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   constexpr int NT = 256;
   constexpr int BM = LSTM_BM, BN = 4 * LSTM_BJ;
@@ -832,15 +858,9 @@ __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   for (int q = 0; q < 4; ++q) {
     const int row = (tid >> 5) + 8 * q;
     const int gm = m0 + row;
-    if (gm < p.N) {
-      const float ig = fast_sigmoid(Zs[0][row][tid & 31]);
-      const float fg = fast_sigmoid(Zs[1][row][tid & 31]);
-      const float gg = fast_tanh(Zs[2][row][tid & 31]);
-      const float og = fast_sigmoid(Zs[3][row][tid & 31]);
-      const float c_new = fg * p.c[(size_t)gm * p.H + j] + ig * gg;
-      p.c_out[(size_t)gm * p.H + j] = c_new;
-      p.h_out[(size_t)gm * p.H + j] = og * fast_tanh(c_new);
-    }
+    if (gm < p.N)
+      cell_update<CELL>(p, (size_t)gm * p.H + j, Zs[0][row][tid & 31], Zs[1][row][tid & 31],
+                        Zs[2][row][tid & 31], Zs[3][row][tid & 31]);
   }
 }
 
@@ -858,6 +878,7 @@ constexpr int LW_BM = 96;
 constexpr int LW_BK = 64;
 constexpr int LW_NT = 768;
 
+template <int CELL>
 __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))) void lstm_f32_wide_kernel(LstmArgs p) {
   constexpr int BM = LW_BM, BN = 128, LBK = LW_BK, KQ = LBK / 4;
   constexpr int A_BYTES = 2 * KQ * (BM + 1) * 16;
@@ -1006,16 +1027,9 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
   for (int q = 0; q < BM * 32 / LW_NT; ++q) {
     const int row = (tid >> 5) + (LW_NT / 32) * q;
     const int gm = m0 + row;
-    if (gm < p.N) {
-      const float ig = fast_sigmoid(Zs[0][row][u]);
-      const float fg = fast_sigmoid(Zs[1][row][u]);
-      const float gg = fast_tanh(Zs[2][row][u]);
-      const float og = fast_sigmoid(Zs[3][row][u]);
-      const size_t o = (size_t)gm * p.H + j0 + u;
-      const float c_new = fg * p.c[o] + ig * gg;
-      p.c_out[o] = c_new;
-      p.h_out[o] = og * fast_tanh(c_new);
-    }
+    if (gm < p.N)
+      cell_update<CELL>(p, (size_t)gm * p.H + j0 + u, Zs[0][row][u], Zs[1][row][u], Zs[2][row][u],
+                        Zs[3][row][u]);
   }
 }
 
@@ -1128,23 +1142,25 @@ int dense_topk_f32(const float* x, const float* w, const float* bias, int M, int
   return ICAP_OK;
 }
 
-int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
-                  const float* emb_proj, const float* h, const float* c, const float* kernel,
-                  const float* recurrent, const float* bias, float* h_out, float* c_out, int N,
-                  int C, int E, int H, int V, hipStream_t s) {
-  ICAP_REQUIRE(ctx && h && c && kernel && recurrent && bias && h_out && c_out,
-               "lstm_step_f32: null pointer");
+namespace {
+
+template <int CELL>
+int cell_step_f32(const char* who, const float* ctx, const float* emb, const float* table,
+                  const int32_t* ids, const float* emb_proj, const float* h, const float* c,
+                  const float* kernel, const float* recurrent, const float* bias, float* h_out,
+                  float* c_out, int N, int C, int E, int H, int V, hipStream_t s) {
+  ICAP_REQUIRE(ctx && h && kernel && recurrent && bias && h_out, "%s: null pointer", who);
+  ICAP_REQUIRE(CELL != CELL_LSTM || (c && c_out), "%s: null pointer", who);
   ICAP_REQUIRE((ids && (table || emb_proj)) || (!ids && emb && !emb_proj),
-               "lstm_step_f32: pass (table, ids), (emb_proj, ids) or emb");
-  ICAP_REQUIRE(N > 0 && C > 0 && E > 0 && H > 0, "lstm_step_f32: bad shape");
-  ICAP_REQUIRE(!ids || V > 0, "lstm_step_f32: V must be positive with ids");
-  ICAP_REQUIRE(h_out != h && c_out != h, "lstm_step_f32: outputs must not alias h");
+               "%s: pass (table, ids), (emb_proj, ids) or emb", who);
+  ICAP_REQUIRE(N > 0 && C > 0 && E > 0 && H > 0, "%s: bad shape", who);
+  ICAP_REQUIRE(!ids || V > 0, "%s: V must be positive with ids", who);
+  ICAP_REQUIRE(h_out != h && c_out != h, "%s: outputs must not alias h", who);
   // With the pre-multiplied embedding the GEMM runs over [ctx | h] only (K = C + H): the
   // kernel sees E = 0 and adds emb_proj[id] in its epilogue.
   const int e_gemm = emb_proj ? 0 : E;
   LstmArgs a{ctx, emb, table, ids, h, c, kernel, recurrent, bias, emb_proj, h_out, c_out,
              N, C, e_gemm, H, V, ceil_div(N, LSTM_BM), ceil_div(H, LSTM_BJ)};
-  if (emb_proj) a.recurrent = recurrent;  // rows C.. of the B operand come from `recurrent`
   const bool vec = (C % 4 == 0) && (E % 4 == 0) && (H % 4 == 0) && aligned16(ctx) &&
                    (emb_proj || aligned16(ids ? table : emb)) && aligned16(h) &&
                    aligned16(kernel) && aligned16(recurrent);
@@ -1161,18 +1177,79 @@ int lstm_step_f32(const float* ctx, const float* emb, const float* table, const 
       LstmArgs w = a;
       w.tiles_m = ceil_div(N, LW_BM);
       w.tiles_j = H / 32;
-      hipLaunchKernelGGL(lstm_f32_wide_kernel, dim3(wide_grid), dim3(LW_NT), 0, s, w);
+      hipLaunchKernelGGL(lstm_f32_wide_kernel<CELL>, dim3(wide_grid), dim3(LW_NT), 0, s, w);
       ICAP_LAUNCH_CHECK("lstm_f32_wide_kernel");
       return ICAP_OK;
     }
   }
   const int grid = a.tiles_m * a.tiles_j;
   if (vec)
-    hipLaunchKernelGGL(lstm_f32_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm_f32_kernel<true, CELL>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(lstm_f32_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm_f32_kernel<false, CELL>), dim3(grid), dim3(256), 0, s, a);
   ICAP_LAUNCH_CHECK("lstm_f32_kernel");
   return ICAP_OK;
+}
+
+// Keras GRUCell variables (reset_after=True: kernel [CE,3H], recurrent_kernel [H,3H], bias
+// [2,3H], gates z, r, h) laid out as four pre-activation columns per unit so that the LSTM
+// gate product serves the GRU: z and r sum the input and the recurrent part, the candidate
+// keeps them apart (x_h from the input rows only, rec_h from the recurrent rows only; the
+// other rows of those two columns are zero, which adds exact zeros to the sums).
+__global__ void gru_pack_kernel(const float* __restrict__ kernel, const float* __restrict__ recurrent,
+                                const float* __restrict__ bias, float* __restrict__ kernel4,
+                                float* __restrict__ recurrent4, float* __restrict__ bias4, int CE,
+                                int H) {
+  const long long total = (long long)(CE + H + 1) * 4 * H;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (4 * H));
+    const int row = (int)(i / (4 * H));
+    const int g = col / H, j = col % H;
+    if (row < CE) {
+      kernel4[(size_t)row * 4 * H + col] = g < 3 ? kernel[(size_t)row * 3 * H + g * H + j] : 0.f;
+    } else if (row < CE + H) {
+      const int r = row - CE;
+      const int src = g < 2 ? g : 2;  // rec_h is the third recurrent gate
+      recurrent4[(size_t)r * 4 * H + col] = g == 2 ? 0.f : recurrent[(size_t)r * 3 * H + src * H + j];
+    } else {
+      // bias[0] is the input bias, bias[1] the recurrent bias
+      const float bi = g < 3 ? bias[g * H + j] : 0.f;
+      const float br = g < 2 ? bias[3 * H + g * H + j] : (g == 3 ? bias[3 * H + 2 * H + j] : 0.f);
+      bias4[col] = g < 2 ? bi + br : (g == 2 ? bi : br);
+    }
+  }
+}
+
+}  // namespace
+
+int lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
+                  const float* emb_proj, const float* h, const float* c, const float* kernel,
+                  const float* recurrent, const float* bias, float* h_out, float* c_out, int N,
+                  int C, int E, int H, int V, hipStream_t s) {
+  return cell_step_f32<CELL_LSTM>("lstm_step_f32", ctx, emb, table, ids, emb_proj, h, c, kernel,
+                                  recurrent, bias, h_out, c_out, N, C, E, H, V, s);
+}
+
+int gru_pack_f32(const float* kernel, const float* recurrent, const float* bias, float* kernel4,
+                 float* recurrent4, float* bias4, int CE, int H, hipStream_t s) {
+  ICAP_REQUIRE(kernel && recurrent && bias && kernel4 && recurrent4 && bias4,
+               "gru_pack_f32: null pointer");
+  ICAP_REQUIRE(CE > 0 && H > 0, "gru_pack_f32: bad shape");
+  const long long total = (long long)(CE + H + 1) * 4 * H;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(gru_pack_kernel, dim3(grid), dim3(256), 0, s, kernel, recurrent, bias, kernel4,
+                     recurrent4, bias4, CE, H);
+  ICAP_LAUNCH_CHECK("gru_pack_kernel");
+  return ICAP_OK;
+}
+
+int gru_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,
+                 const float* emb_proj, const float* h, const float* kernel4,
+                 const float* recurrent4, const float* bias4, float* h_out, int N, int C, int E,
+                 int H, int V, hipStream_t s) {
+  return cell_step_f32<CELL_GRU>("gru_step_f32", ctx, emb, table, ids, emb_proj, h, nullptr, kernel4,
+                                 recurrent4, bias4, h_out, nullptr, N, C, E, H, V, s);
 }
 
 }  // namespace icap

@@ -2,3 +2,4 @@ from .decoder import Decoder  # noqa: F401
 from .embedding import EmbeddingLayer  # noqa: F401
 from .init_state import FeatureProjState  # noqa: F401
 from .lstm_recurrent_decoder import LstmDecoder  # noqa: F401
+from .recurrent_decoder import RecurrentDecoder  # noqa: F401

@@ -13,6 +13,7 @@ from . import _lib, ops
 TILE_MODES = {"reference": _lib.TILE_REFERENCE, "repeat": _lib.TILE_REPEAT}
 PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16,
               "fp32_split": _lib.PRECISION_F32_SPLIT}
+CELLS = {"lstm": _lib.CELL_LSTM, "gru": _lib.CELL_GRU}
 
 # checkpoint (.npz) parameter name -> icap_weights field
 PARAM_TO_FIELD = {
@@ -27,6 +28,13 @@ PARAM_TO_FIELD = {
     "lstm_bias": "lstm_bias", "fc1_kernel": "fc1_kernel", "fc1_bias": "fc1_bias",
     "fc2_kernel": "fc2_kernel", "fc2_bias": "fc2_bias",
 }
+# the GRU decoder's variables travel in the cell slots of icap_weights; it has one state,
+# so the second init-state projection is absent
+GRU_PARAM_TO_FIELD = {k: v for k, v in PARAM_TO_FIELD.items()
+                      if not k.startswith(("lstm_", "init1_"))}
+GRU_PARAM_TO_FIELD.update({"gru_kernel": "lstm_kernel",
+                           "gru_recurrent_kernel": "lstm_recurrent_kernel",
+                           "gru_bias": "lstm_bias"})
 
 
 @dataclass
@@ -49,6 +57,7 @@ class CaptionConfig:
     reset_state_from_feat: float = 1.0
     tile_mode: str = "reference"
     precision: str = "fp32"
+    cell: str = "lstm"            # "gru": the RecurrentDecoder sibling (decoder/recurrent_decoder.py)
 
     @property
     def N(self):
@@ -63,6 +72,8 @@ class CaptionEngine:
             raise ValueError("tile_mode must be 'reference' or 'repeat'")
         if config.precision not in PRECISIONS:
             raise ValueError("precision must be 'fp32', 'fp32_split' or 'bf16'")
+        if config.cell not in CELLS:
+            raise ValueError("cell must be 'lstm' or 'gru'")
         self.config = config
         self.device = torch.device(device) if device is not None else \
             torch.device("cuda", torch.cuda.current_device())
@@ -71,7 +82,8 @@ class CaptionEngine:
         # device copies of the weights (kept alive by this object)
         self.weights = {}
         w = _lib.IcapWeights()
-        for pname, field in PARAM_TO_FIELD.items():
+        names = GRU_PARAM_TO_FIELD if config.cell == "gru" else PARAM_TO_FIELD
+        for pname, field in names.items():
             if pname not in params:
                 raise KeyError("missing parameter %r" % pname)
             t = params[pname]
@@ -87,7 +99,8 @@ class CaptionEngine:
                             tile_mode=TILE_MODES[config.tile_mode],
                             precision=PRECISIONS[config.precision],
                             length_penalty_weight=float(config.length_penalty_weight),
-                            reset_state_from_feat=float(config.reset_state_from_feat), reserved=0)
+                            reset_state_from_feat=float(config.reset_state_from_feat),
+                            cell=CELLS[config.cell])
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(lib.icap_engine_create(C.byref(c), C.byref(w), C.byref(handle)))
@@ -104,6 +117,10 @@ class CaptionEngine:
             "lstm_kernel": (c.D + c.E, 4 * c.H), "lstm_recurrent_kernel": (c.H, 4 * c.H),
             "lstm_bias": (4 * c.H,), "fc1_kernel": (c.H, c.H), "fc1_bias": (c.H,),
             "fc2_kernel": (c.H, c.V), "fc2_bias": (c.V,)}
+        if c.cell == "gru":
+            del expect["init_c_kernel"], expect["init_c_bias"]
+            expect.update({"lstm_kernel": (c.D + c.E, 3 * c.H),
+                           "lstm_recurrent_kernel": (c.H, 3 * c.H), "lstm_bias": (2, 3 * c.H)})
         for k, shape in expect.items():
             if tuple(w[k].shape) != shape:
                 raise ValueError("weight %s has shape %s, expected %s" % (k, tuple(w[k].shape), shape))
@@ -187,26 +204,32 @@ class CaptionEngine:
 
 
 def params_from_modules(encoder, decoder):
-    """Collects the device weights of an MlpEncoder + LstmDecoder pair under the
-    engine's parameter names."""
+    """Collects the device weights of an MlpEncoder + LstmDecoder (or RecurrentDecoder) pair
+    under the engine's parameter names."""
     from .decoder.embedding import EmbeddingLayer
     emb = decoder.embedding_layer
     if not isinstance(emb, EmbeddingLayer):
         raise TypeError("sequence_beam_search needs decoder.embedding_layer to be an "
                         "EmbeddingLayer so the engine can read the table")
     att = decoder.attention
+    if hasattr(decoder, "gru"):
+        cell = {"gru_kernel": decoder.gru.kernel,
+                "gru_recurrent_kernel": decoder.gru.recurrent_kernel, "gru_bias": decoder.gru.bias}
+    else:
+        cell = {"init1_kernel": decoder.feat_proj_state_vec[1].fc.kernel,
+                "init1_bias": decoder.feat_proj_state_vec[1].fc.bias,
+                "lstm_kernel": decoder.lstm.kernel,
+                "lstm_recurrent_kernel": decoder.lstm.recurrent_kernel,
+                "lstm_bias": decoder.lstm.bias}
     return {
+        **cell,
         "enc_kernel": encoder.fc.kernel, "enc_bias": encoder.fc.bias, "embedding": emb.table,
         "init0_kernel": decoder.feat_proj_state_vec[0].fc.kernel,
         "init0_bias": decoder.feat_proj_state_vec[0].fc.bias,
-        "init1_kernel": decoder.feat_proj_state_vec[1].fc.kernel,
-        "init1_bias": decoder.feat_proj_state_vec[1].fc.bias,
         "att_W1_kernel": att.W1.kernel, "att_W1_bias": att.W1.bias,
         "att_W2_kernel": att.W2.kernel, "att_W2_bias": att.W2.bias,
         "att_V_kernel": att.V.kernel, "att_V_bias": att.V.bias,
         "fc3_kernel": decoder.fc3.kernel, "fc3_bias": decoder.fc3.bias,
-        "lstm_kernel": decoder.lstm.kernel,
-        "lstm_recurrent_kernel": decoder.lstm.recurrent_kernel, "lstm_bias": decoder.lstm.bias,
         "fc1_kernel": decoder.fc1.kernel, "fc1_bias": decoder.fc1.bias,
         "fc2_kernel": decoder.fc2.kernel, "fc2_bias": decoder.fc2.bias,
     }
@@ -233,7 +256,8 @@ def sequence_beam_search(encoder, decoder, img, beam_width, max_len, start_id, e
                         V=decoder.vocab_size, T=max_len, start_id=start_id, eos_id=eos_id,
                         length_penalty_weight=length_penalty_weight,
                         reset_state_from_feat=float(decoder.reset_state_from_feat),
-                        tile_mode=tile_mode, precision=precision)
+                        tile_mode=tile_mode, precision=precision,
+                        cell="gru" if hasattr(decoder, "gru") else "lstm")
     key = (id(encoder), id(decoder), tuple(sorted(cfg.__dict__.items())),
            tuple((k, v.data_ptr()) for k, v in sorted(p.items())), str(img.device))
     eng = _engine_cache.get(key)

@@ -124,6 +124,48 @@ def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, i
     return h_out, c_out
 
 
+def gru_pack(kernel, recurrent_kernel, bias):
+    """Keras GRUCell variables (kernel [CE,3H], recurrent_kernel [H,3H], bias [2,3H]) re-laid
+    as the four-column operands gru_step takes: (kernel4 [CE,4H], recurrent4 [H,4H],
+    bias4 [4H])."""
+    CE, H3 = kernel.shape
+    H = H3 // 3
+    if H3 != 3 * H or recurrent_kernel.shape != (H, 3 * H) or bias.numel() != 6 * H:
+        raise ValueError("gru_pack: expected kernel [CE,3H], recurrent_kernel [H,3H], bias [2,3H]")
+    k4 = torch.empty(CE, 4 * H, dtype=f32, device=kernel.device)
+    r4 = torch.empty(H, 4 * H, dtype=f32, device=kernel.device)
+    b4 = torch.empty(4 * H, dtype=f32, device=kernel.device)
+    _lib.call("icap_gru_pack_f32", _chk(kernel, f32, "kernel"),
+              _chk(recurrent_kernel, f32, "recurrent_kernel"), _chk(bias, f32, "bias"),
+              k4.data_ptr(), r4.data_ptr(), b4.data_ptr(), CE, H, current_stream())
+    return k4, r4, b4
+
+
+def gru_step(ctx, h, kernel4, recurrent4, bias4, emb=None, table=None, ids=None, emb_proj=None):
+    """One GRU cell step on [ctx | emb | h] with operands from gru_pack; returns h'.  Pass
+    emb[N,E], or ids[N] with table[V,E] and/or emb_proj[V,4H] = table . kernel4[C:C+E]."""
+    N, Cdim = ctx.shape
+    H = h.shape[1]
+    if ids is not None:
+        ids = ids.reshape(-1)
+        if emb_proj is not None:
+            V = emb_proj.shape[0]
+            E = kernel4.shape[0] - Cdim
+        else:
+            V, E = table.shape
+    else:
+        V, E = 0, emb.shape[1]
+    if kernel4.shape != (Cdim + E, 4 * H) or recurrent4.shape != (H, 4 * H):
+        raise ValueError("gru_step: packed kernel shapes do not match [C+E,4H] / [H,4H]")
+    h_out = torch.empty_like(h)
+    _lib.call("icap_gru_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
+              _opt(table, f32, "table"), _opt(ids, i32, "ids"), _opt(emb_proj, f32, "emb_proj"),
+              _chk(h, f32, "h"), _chk(kernel4, f32, "kernel4"), _chk(recurrent4, f32, "recurrent4"),
+              _chk(bias4, f32, "bias4"), _chk(h_out, f32, "h_out"), N, Cdim, E, H, V,
+              current_stream())
+    return h_out
+
+
 _beam_ws = {}
 
 

@@ -45,6 +45,20 @@ def make_params(seed, F, D, E, H, V, U=None):
     return p
 
 
+def add_gru_params(p, seed):
+    """GRU variables for the GRU decoder (reference decoder/recurrent_decoder.py:30-34) beside
+    the LSTM ones, from a random stream of their own: Glorot-uniform kernel [D+E,3H] and
+    recurrent kernel [H,3H], zero bias [2,3H]."""
+    rng = np.random.default_rng([seed, 7919])
+    CE = p["lstm_kernel"].shape[0]
+    H = p["lstm_recurrent_kernel"].shape[0]
+    q = dict(p)
+    q["gru_kernel"] = _glorot(rng, CE, 3 * H)
+    q["gru_recurrent_kernel"] = _glorot(rng, H, 3 * H)
+    q["gru_bias"] = np.zeros((2, 3 * H), np.float32)
+    return q
+
+
 def make_images(seed, B, L, F):
     """max(0, N(0,1)) * 0.5: non-negative, about half zeros, like post-ReLU CNN maps."""
     rng = np.random.default_rng(seed)

@@ -45,6 +45,9 @@ extern "C" {
                                     * partial products of weight >= 2^-16 summed in fp32 */
 #define ICAP_PRECISION_BF16 1 /* bf16 operands on MFMA for every dense contraction, f32 accumulate */
 
+#define ICAP_CELL_LSTM 0 /* decoder/lstm_recurrent_decoder.py: state [h, c], query and beta gate from c */
+#define ICAP_CELL_GRU 1  /* decoder/recurrent_decoder.py: state [h], query and beta gate from h */
+
 #define ICAP_MAX_BEAM_WIDTH 16
 
 typedef void* icap_stream_t;
@@ -115,6 +118,26 @@ int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table,
                        const float* c, const float* kernel, const float* recurrent_kernel,
                        const float* bias, float* h_out, float* c_out,
                        int N, int C, int E, int H, int V, icap_stream_t stream);
+
+/* One Keras GRUCell step (TF 2.3 defaults: reset_after=True, gates z, r, h) with the same
+ * input handling as icap_lstm_step_f32:
+ *   x = [ctx | emb_n];  mx = x . kernel + bias[0];  mh = h . recurrent_kernel + bias[1]
+ *   z = sig(mx_z + mh_z);  r = sig(mx_r + mh_r);  hh = tanh(mx_h + r*mh_h)
+ *   h' = z*h + (1-z)*hh
+ * The product runs on the LSTM gate kernels over operands re-laid as four columns per unit
+ * (z, r, x_h, rec_h; zero rows where a column has no input or no recurrent part):
+ * icap_gru_pack_f32 builds kernel4 [CE,4H], recurrent4 [H,4H], bias4 [4H] from the Keras
+ * variables kernel [CE,3H], recurrent_kernel [H,3H], bias [2,3H] (CE = C+E), once per
+ * weight version.  emb_proj (optional, with ids) = table . kernel4[C:C+E], [V,4H].
+ * h_out must be a different buffer from h.
+ * Replaces tf.concat + tf.keras.layers.GRUCell at decoder/recurrent_decoder.py:97-99. */
+int icap_gru_pack_f32(const float* kernel, const float* recurrent_kernel, const float* bias,
+                      float* kernel4, float* recurrent4, float* bias4, int CE, int H,
+                      icap_stream_t stream);
+int icap_gru_step_f32(const float* ctx, const float* emb, const float* table,
+                      const int32_t* ids, const float* emb_proj, const float* h,
+                      const float* kernel4, const float* recurrent4, const float* bias4,
+                      float* h_out, int N, int C, int E, int H, int V, icap_stream_t stream);
 
 /* ---- bf16-operand mode (ICAP_PRECISION_BF16) -------------------------------------
  * The dense contractions take bf16 operands (round-to-nearest-even) and accumulate in
@@ -272,21 +295,21 @@ typedef struct icap_config {
   int32_t precision;            /* ICAP_PRECISION_* */
   double length_penalty_weight; /* a double: 6^w is folded in double, beam_search.py:127 */
   float reset_state_from_feat;  /* decoder/lstm_recurrent_decoder.py:129 */
-  int32_t reserved;
+  int32_t cell;                 /* ICAP_CELL_* (0 = LSTM, the field was reserved-as-zero before) */
 } icap_config;
 
 typedef struct icap_weights { /* device pointers; must outlive the engine */
   const float* enc_kernel;  const float* enc_bias;        /* [F,D], [D]   */
   const float* embedding;                                 /* [V,E]        */
   const float* init_h_kernel; const float* init_h_bias;   /* [D,H], [H]   */
-  const float* init_c_kernel; const float* init_c_bias;   /* [D,H], [H]   */
+  const float* init_c_kernel; const float* init_c_bias;   /* [D,H], [H]   (GRU: unused, may be NULL) */
   const float* att_w1_kernel; const float* att_w1_bias;   /* [D,U], [U]   */
   const float* att_w2_kernel; const float* att_w2_bias;   /* [H,U], [U]   */
   const float* att_v_kernel;  const float* att_v_bias;    /* [U,1], [1]   */
   const float* fc3_kernel;    const float* fc3_bias;      /* [H,1], [1]   */
-  const float* lstm_kernel;                               /* [D+E,4H]     */
-  const float* lstm_recurrent_kernel;                     /* [H,4H]       */
-  const float* lstm_bias;                                 /* [4H]         */
+  const float* lstm_kernel;                               /* [D+E,4H]   (GRU: [D+E,3H]) */
+  const float* lstm_recurrent_kernel;                     /* [H,4H]     (GRU: [H,3H])   */
+  const float* lstm_bias;                                 /* [4H]       (GRU: [2,3H])   */
   const float* fc1_kernel;    const float* fc1_bias;      /* [H,H], [H]   */
   const float* fc2_kernel;    const float* fc2_bias;      /* [H,V], [V]   */
 } icap_weights;

@@ -153,6 +153,55 @@ def lstm_decoder_step(p, dec_input, features, hidden, bias=None, w1f=None):
     return logits, state, weights, context
 
 
+def gru_cell(x, h_tm1, kernel, recurrent_kernel, bias):
+    """Keras `GRUCell.call` (TF 2.3 defaults: reset_after=True, implementation=2, tanh /
+    sigmoid; variables kernel [in,3H], recurrent_kernel [H,3H], bias [2,3H] = input bias,
+    recurrent bias; gate order z, r, h):
+    mx = x.kernel + bias[0]; mh = h.recurrent_kernel + bias[1];
+    z = sig(mx_z + mh_z); r = sig(mx_r + mh_r); hh = tanh(mx_h + r*mh_h);
+    h' = z*h + (1-z)*hh.  Returns (h', [h'])."""
+    mx = np.matmul(x, kernel) + bias[0]
+    mh = np.matmul(h_tm1, recurrent_kernel) + bias[1]
+    x_z, x_r, x_h = np.split(mx, 3, axis=-1)
+    r_z, r_r, r_h = np.split(mh, 3, axis=-1)
+    z = sigmoid(x_z + r_z)
+    r = sigmoid(x_r + r_r)
+    hh = np.tanh(x_h + r * r_h)
+    h = z * h_tm1 + (1 - z) * hh
+    return h, [h]
+
+
+def gru_decoder_step(p, dec_input, features, hidden, bias=None, w1f=None):
+    """`RecurrentDecoder.call` (`decoder/recurrent_decoder.py:56-115`): the LSTM decoder's
+    skeleton with one state h: the attention query (`:77`) and the beta gate (`:90`) read
+    h, the cell is a GRUCell on [context, embedding] (`:97-99`), fc1 has no activation
+    (`:103`).  Returns (logits[N,V], [h], weights[N,L,1], context[N,D] times beta)."""
+    ids = np.asarray(dec_input).reshape(-1)
+    emb = embedding_lookup(p["embedding"], ids)
+    h_state = hidden[0]
+    context, weights = bahdanau_attention(features, h_state, p, bias=bias, w1f=w1f)
+    beta = sigmoid(dense(h_state, p["fc3_kernel"], p["fc3_bias"]))
+    context = context * beta
+    gru_input = np.concatenate([context, emb], axis=-1)
+    output, state = gru_cell(gru_input, h_state, p["gru_kernel"], p["gru_recurrent_kernel"],
+                             p["gru_bias"])
+    output = dense(output, p["fc1_kernel"], p["fc1_bias"])
+    logits = dense(output, p["fc2_kernel"], p["fc2_bias"])
+    return logits, state, weights, context
+
+
+def reset_state_gru(p, batch_size, features, reset_state_from_feat=1, bias=None):
+    """`RecurrentDecoder.reset_state` (`decoder/recurrent_decoder.py:117-127`): one state,
+    h = 0 + reset_state_from_feat * FeatureProjState_0(features)."""
+    units = p["gru_recurrent_kernel"].shape[0]
+    dt = p["gru_kernel"].dtype
+    zeros = np.zeros((batch_size, units), dtype=dt)
+    if features is None:
+        return [zeros]
+    proj = feature_proj_state(features, p["init0_kernel"], p["init0_bias"], mask=bias)
+    return [zeros + dt.type(reset_state_from_feat) * proj]
+
+
 def reset_state(p, batch_size, features, reset_state_from_feat=1, bias=None):
     """`LstmDecoder.reset_state` (`decoder/lstm_recurrent_decoder.py:118-131`):
     state_idx = 0 + reset_state_from_feat * FeatureProjState_idx(features)."""
@@ -367,7 +416,7 @@ def tile_features(features, beam_width, tile_mode):
 def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id,
                                    length_penalty_weight=1.0, tile_mode="reference",
                                    reset_state_from_feat=1, return_trace=False,
-                                   hoist_w1=False):
+                                   hoist_w1=False, cell="lstm"):
     """`predict_image_caption_sequence` (`recurrent_example.py:477-562`).
 
     encoder -> tile -> reset_state -> T x (decoder step, beam step) -> back-track.
@@ -375,13 +424,20 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     `:558`): only the token ids come from the beam search.  No early exit (`:517`).
     `hoist_w1` computes the step-invariant W1(features) once instead of every step (same
     values; a faster CPU variant used as a second baseline by the benchmark).
+    `cell="gru"` runs the same loop over the GRU sibling decoder
+    (`decoder/recurrent_decoder.py`; no driver in the reference constructs it, the loop is
+    the LSTM one with the decoder swapped).
     Returns int32 tokens [B,T] (and the per-step trace if asked)."""
+    if cell not in ("lstm", "gru"):
+        raise ValueError("cell must be 'lstm' or 'gru'")
+    step_fn = lstm_decoder_step if cell == "lstm" else gru_decoder_step
+    reset_fn = reset_state if cell == "lstm" else reset_state_gru
     B = img.shape[0]
     W = beam_width
     features = mlp_encoder(img, p["enc_kernel"], p["enc_bias"])
     features = tile_features(features, W, tile_mode)
     dec_input = np.full([B * W, 1], start_id, np.int32)
-    hidden = reset_state(p, B * W, features, reset_state_from_feat)
+    hidden = reset_fn(p, B * W, features, reset_state_from_feat)
     V = p["fc2_kernel"].shape[1]
     state = create_initial_beam_state_batch(B, W, dtype=img.dtype)
     config = BeamSearchConfig(W, V, eos_id, length_penalty_weight, choose_top_k)
@@ -389,13 +445,13 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     trace = []
     w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"]) if hoist_w1 else None
     for i in range(max_len):
-        logits, hidden, weights, ctx = lstm_decoder_step(p, dec_input, features, hidden, w1f=w1f)
+        logits, hidden, weights, ctx = step_fn(p, dec_input, features, hidden, w1f=w1f)
         logits3 = logits.reshape(-1, W, V)
         out, state = beam_search_step_batch(i, logits3, state, config)
         seq.append((out, state))
         if return_trace:
             trace.append({"logits": logits3, "out": out, "state": state,
-                          "h": hidden[0], "c": hidden[1], "ctx": ctx,
+                          "h": hidden[0], "c": hidden[-1], "ctx": ctx,
                           "weights": weights})
         dec_input = out.predicted_ids.reshape(-1, 1)
     path = loc_optimal_beam_path_batch(seq)
@@ -447,6 +503,21 @@ def make_params(seed, F, D, E, H, V, U=None, C=None):
     p["fc2_kernel"] = _glorot(rng, H, V)
     p["fc2_bias"] = np.zeros(V, np.float32)
     return p
+
+
+def add_gru_params(p, seed):
+    """GRU variables for the sibling decoder beside the LSTM ones of `make_params` (own
+    random stream, so the LSTM parameters of a seed do not change): Glorot-uniform kernels
+    (`recurrent_decoder.py:21,33` asks for a glorot_uniform recurrent kernel), zero bias
+    [2,3H] (Keras GRUCell default with reset_after=True)."""
+    rng = np.random.default_rng([seed, 7919])
+    CE = p["lstm_kernel"].shape[0]
+    H = p["lstm_recurrent_kernel"].shape[0]
+    q = dict(p)
+    q["gru_kernel"] = _glorot(rng, CE, 3 * H)
+    q["gru_recurrent_kernel"] = _glorot(rng, H, 3 * H)
+    q["gru_bias"] = np.zeros((2, 3 * H), np.float32)
+    return q
 
 
 def perturb_biases(p, seed, scale=0.05):

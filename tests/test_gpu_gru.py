@@ -1,0 +1,182 @@
+"""GRU decoder (reference decoder/recurrent_decoder.py) vs the oracle: the cell step, the
+decoder module and the whole-sequence decode with cell="gru".
+
+No reference test or fixture covers this decoder (no driver in the reference constructs
+it): parity unpinned, the checker is the oracle's restatement of recurrent_decoder.py and
+of the Keras GRUCell contract.  Bars as for the LSTM path: 1e-5 relative on states and
+log-probs, identical tokens except proven fp32 near-ties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caption_oracle as co
+from tests.helpers import assert_close, dev, np_of, to_dev
+from tests.test_gpu_e2e import SMALL, _first_divergence, _oracle_margin
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from image_caption_amd import ops as o
+    return o
+
+
+def test_gru_pack_layout(ops):
+    rng = np.random.default_rng(0)
+    CE, H = 7, 5
+    k = rng.standard_normal((CE, 3 * H)).astype(np.float32)
+    r = rng.standard_normal((H, 3 * H)).astype(np.float32)
+    b = rng.standard_normal((2, 3 * H)).astype(np.float32)
+    k4, r4, b4 = (np_of(t) for t in ops.gru_pack(to_dev(k), to_dev(r), to_dev(b)))
+    np.testing.assert_array_equal(k4[:, :3 * H], k)
+    np.testing.assert_array_equal(k4[:, 3 * H:], 0)
+    np.testing.assert_array_equal(r4[:, :2 * H], r[:, :2 * H])
+    np.testing.assert_array_equal(r4[:, 2 * H:3 * H], 0)
+    np.testing.assert_array_equal(r4[:, 3 * H:], r[:, 2 * H:])
+    np.testing.assert_array_equal(b4[:2 * H], b[0, :2 * H] + b[1, :2 * H])
+    np.testing.assert_array_equal(b4[2 * H:3 * H], b[0, 2 * H:])
+    np.testing.assert_array_equal(b4[3 * H:], b[1, 2 * H:])
+
+
+@pytest.mark.parametrize("N,C,E,H,V,use_ids", [
+    (5, 4, 4, 6, 11, True), (5, 4, 4, 6, 11, False), (7, 6, 5, 9, 13, True),
+    (130, 8, 8, 36, 50, True), (96, 256, 256, 512, 1000, True), (200, 256, 256, 512, 0, False),
+    (1152, 64, 64, 512, 300, True), (1536, 256, 256, 512, 10000, True)])
+def test_gru_step(ops, N, C, E, H, V, use_ids):
+    rng = np.random.default_rng(N + C + H + 1)
+    kernel = (rng.standard_normal((C + E, 3 * H)) / np.sqrt(C + E)).astype(np.float32)
+    rec = (rng.standard_normal((H, 3 * H)) / np.sqrt(H)).astype(np.float32)
+    bias = rng.standard_normal((2, 3 * H)).astype(np.float32) * 0.2
+    ctx = rng.standard_normal((N, C)).astype(np.float32)
+    h = rng.standard_normal((N, H)).astype(np.float32) * 0.5
+    k4, r4, b4 = ops.gru_pack(to_dev(kernel), to_dev(rec), to_dev(bias))
+    if use_ids:
+        table = rng.standard_normal((V, E)).astype(np.float32)
+        ids = rng.integers(0, V, size=N).astype(np.int32)
+        emb = table[ids]
+        h1 = ops.gru_step(to_dev(ctx), to_dev(h), k4, r4, b4, table=to_dev(table), ids=to_dev(ids))
+        emb_proj = ops.dense(to_dev(table), k4[C:].contiguous(), None)
+        h2 = ops.gru_step(to_dev(ctx), to_dev(h), k4, r4, b4, ids=to_dev(ids), emb_proj=emb_proj)
+    else:
+        emb = rng.standard_normal((N, E)).astype(np.float32)
+        h1 = ops.gru_step(to_dev(ctx), to_dev(h), k4, r4, b4, emb=to_dev(emb))
+    x = np.concatenate([ctx, emb], axis=1)
+    h_ref, _ = co.gru_cell(x.astype(np.float64), h.astype(np.float64), kernel.astype(np.float64),
+                           rec.astype(np.float64), bias.astype(np.float64))
+    assert_close(np_of(h1), h_ref, what="gru h")
+    if use_ids:
+        assert_close(np_of(h2), h_ref, what="gru h (emb_proj)")
+
+
+def _gru_modules(p, dims, reset=1):
+    from image_caption_amd.decoder import EmbeddingLayer, RecurrentDecoder
+    from image_caption_amd.encoder import MlpEncoder
+    d = dev()
+    emb = EmbeddingLayer(dims["V"], dims["E"], device=d)
+    enc = MlpEncoder(dims["D"], name="mlp_feature_encoder", device=d)
+    enc.fc.set_weights(p["enc_kernel"], p["enc_bias"], d)
+    dec = RecurrentDecoder(emb, dims["E"], dims["H"], dims["V"], reset_state_from_feat=reset, device=d)
+    dec.load_params(p, d)
+    return enc, dec
+
+
+def _gru_params(seed, dims, bias_seed=None):
+    p = co.add_gru_params(co.make_params(seed, **dims), seed)
+    return co.perturb_biases(p, bias_seed) if bias_seed is not None else p
+
+
+@pytest.mark.parametrize("dims,N,L", [(SMALL, 6, 5), (dict(F=64, D=256, E=256, H=512, V=1000), 12, 64)])
+def test_gru_decoder_step_module(dims, N, L):
+    from image_caption_amd.decoder import RecurrentDecoder
+    p = _gru_params(3, dims, 4)
+    _, dec = _gru_modules(p, dims)
+    rng = np.random.default_rng(5)
+    feats = np.abs(rng.standard_normal((N, L, dims["D"]))).astype(np.float32)
+    ids = rng.integers(0, dims["V"], size=(N, 1)).astype(np.int32)
+    hidden_o = co.reset_state_gru(p, N, feats, 1)
+    hidden_g = dec.reset_state(torch.zeros(N, 1, device=dev()), {"features": to_dev(feats)})
+    assert len(hidden_g) == 1
+    assert_close(np_of(hidden_g[0]), hidden_o[0], what="reset_state")
+    with pytest.raises(KeyError):
+        dec((to_dev(ids), {"features": to_dev(feats)}, hidden_g))
+    feats_g = to_dev(feats)
+    for step in range(3):
+        lo, hidden_o, wo, co_ = co.gru_decoder_step(p, ids, feats, hidden_o)
+        lg, hidden_g, wg, cg = dec((to_dev(ids), {"features": feats_g}, hidden_g), training=False)
+        assert tuple(wg.shape) == (N, L, 1) and tuple(lg.shape) == (N, dims["V"])
+        assert_close(np_of(wg), wo, what="weights step %d" % step)
+        assert_close(np_of(cg), co_, what="context step %d" % step)
+        assert_close(np_of(hidden_g[0]), hidden_o[0], rtol=2e-5, what="h step %d" % step)
+        assert_close(np_of(lg), lo, rtol=3e-5, what="logits step %d" % step)
+        ids = np.argmax(lo, axis=1).astype(np.int32)[:, None]
+    zeros = dec.reset_state(torch.zeros(N, 1, device=dev()), {})
+    assert len(zeros) == 1 and float(zeros[0].abs().sum()) == 0.0
+    assert isinstance(dec.copy(), RecurrentDecoder)
+
+
+def _compare_gru_decode(dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0, **cfg_kw):
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = _gru_params(seed, dims, bias_seed)
+    img = co.make_images(seed + 50, B, L, dims["F"])
+    tok_o, trace_o = co.predict_image_caption_sequence(p, img, W, T, 3, 4, lpw, tile_mode,
+                                                       return_trace=True, cell="gru")
+    cfg = CaptionConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], E=dims["E"], H=dims["H"],
+                        U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
+                        length_penalty_weight=lpw, tile_mode=tile_mode, cell="gru", **cfg_kw)
+    eng = CaptionEngine(cfg, p, device=dev())
+    tok_g, _ = eng.decode(to_dev(img))
+    tr_g = eng.trace()
+    tok_g = np_of(tok_g)
+    bad = [b for b in range(B) if (tok_g[b] != tok_o[b]).any()]
+    explained = []
+    for b in bad:
+        t = _first_divergence(trace_o, tr_g, b)
+        assert t is not None, "image %d: tokens differ but the beam records agree" % b
+        m = _oracle_margin(trace_o, t, b, W, dims["V"], 4, lpw)
+        assert m < 2e-5, "image %d diverges at step %d with oracle margin %.3e" % (b, t, m)
+        explained.append((b, t, m))
+    good = [b for b in range(B) if b not in bad]
+    keep = np.array([_first_divergence(trace_o, tr_g, b) is None for b in good], bool)
+    lp_o = np.stack([st["state"].log_probs for st in trace_o])[:, good][:, keep]
+    lp_g = np_of(tr_g["log_probs"])[:, good][:, keep]
+    with np.errstate(over="ignore"):
+        assert_close(np.maximum(lp_g, -1e30), np.maximum(lp_o, -1e30), rtol=1e-5, what="log_probs")
+    eng.close()
+    return len(bad), explained
+
+
+@pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
+@pytest.mark.parametrize("W", [1, 3])
+def test_gru_decode_small(tile_mode, W):
+    nbad, _ = _compare_gru_decode(SMALL, seed=1, B=5, L=5, T=7, W=W, tile_mode=tile_mode, bias_seed=9)
+    assert nbad == 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
+def test_gru_decode_medium_production_dims(precision):
+    dims = dict(F=2048, D=256, E=256, H=512, V=10000)
+    nbad, explained = _compare_gru_decode(dims, seed=0, B=16, L=64, T=20, W=3, tile_mode="reference",
+                                          precision=precision)
+    assert nbad <= 1, explained
+
+
+def test_gru_sequence_beam_search_entry():
+    from image_caption_amd import sequence_beam_search
+    p = _gru_params(4, SMALL, 5)
+    enc, dec = _gru_modules(p, SMALL)
+    img = co.make_images(6, 4, 5, SMALL["F"])
+    tok_o = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4, 1.0, "reference", cell="gru")
+    tok_g = sequence_beam_search(enc, dec, to_dev(img), 3, 6, 3, 4, tile_mode="reference")
+    np.testing.assert_array_equal(np_of(tok_g), tok_o)
+
+
+def test_gru_rejects_bf16():
+    from image_caption_amd._lib import IcapError
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    dims = dict(F=64, D=64, E=64, H=64, V=128)
+    p = _gru_params(0, dims)
+    cfg = CaptionConfig(B=2, W=2, L=4, F=64, D=64, E=64, H=64, U=64, V=128, T=3, cell="gru",
+                        precision="bf16")
+    with pytest.raises(IcapError):
+        CaptionEngine(cfg, p, device=dev())

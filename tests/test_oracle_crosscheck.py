@@ -47,6 +47,49 @@ def test_lstm_cell_matches_torch_lstmcell():
     assert out is h1
 
 
+def test_gru_cell_matches_torch_grucell():
+    """Keras reset_after=True GRU is torch's GRUCell with the gates reordered
+    (Keras z, r, h; torch r, z, n) and the two bias rows as bias_ih / bias_hh."""
+    p = co.perturb_biases(co.add_gru_params(_params(2), 2), 3, scale=0.2)
+    rng = np.random.default_rng(6)
+    n, H = 7, DIMS["H"]
+    x = rng.standard_normal((n, DIMS["D"] + DIMS["E"])).astype(np.float32)
+    h = rng.standard_normal((n, H)).astype(np.float32) * 0.3
+
+    def reorder(a):                       # columns [z | r | h] -> [r | z | h]
+        z, r, c = np.split(a, 3, axis=-1)
+        return np.concatenate([r, z, c], axis=-1)
+
+    cell = torch.nn.GRUCell(x.shape[1], H)
+    with torch.no_grad():
+        cell.weight_ih.copy_(_t(reorder(p["gru_kernel"])).T)
+        cell.weight_hh.copy_(_t(reorder(p["gru_recurrent_kernel"])).T)
+        cell.bias_ih.copy_(_t(reorder(p["gru_bias"][0])))
+        cell.bias_hh.copy_(_t(reorder(p["gru_bias"][1])))
+        h_ref = cell(_t(x), _t(h))
+    out, (h1,) = co.gru_cell(x, h, p["gru_kernel"], p["gru_recurrent_kernel"], p["gru_bias"])
+    np.testing.assert_allclose(h1, h_ref.numpy(), rtol=1e-5, atol=1e-6)
+    assert out is h1
+
+
+def test_gru_decoder_uses_h_as_query_and_single_state():
+    p = co.add_gru_params(_params(4), 4)
+    rng = np.random.default_rng(7)
+    n, L = 3, 4
+    feats = np.abs(rng.standard_normal((n, L, DIMS["D"]))).astype(np.float32)
+    hidden = co.reset_state_gru(p, n, feats, 1)
+    assert len(hidden) == 1
+    ids = np.array([[1], [2], [3]], np.int32)
+    logits, state, weights, ctx = co.gru_decoder_step(p, ids, feats, hidden)
+    assert len(state) == 1 and logits.shape == (n, DIMS["V"]) and weights.shape == (n, L, 1)
+    c0, _ = co.bahdanau_attention(feats, hidden[0], p)
+    beta = co.sigmoid(co.dense(hidden[0], p["fc3_kernel"], p["fc3_bias"]))
+    np.testing.assert_allclose(ctx, c0 * beta, rtol=1e-6)
+    tok = co.predict_image_caption_sequence(p, co.make_images(1, 2, L, DIMS["F"]), 2, 5, 3, 4,
+                                            cell="gru")
+    assert tok.shape == (2, 5)
+
+
 def test_attention_matches_torch():
     p = _params(3)
     rng = np.random.default_rng(6)
