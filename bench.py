@@ -36,6 +36,10 @@ CONFIGS = {
     # the headline shape over the GRU sibling decoder (decoder/recurrent_decoder.py)
     "beam3_b512_fp32_gru": dict(B=512, W=3, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000,
                                 T=20, precision="fp32", cell="gru"),
+    # the baseline beam searcher of the sequence-level trainers (utils/agent_utils.py:134-262)
+    # at the headline shape: encoded features in, start-token mask, time from 1, 20 steps
+    "searcher_b512_fp32": dict(B=512, W=3, L=64, F=256, D=256, E=256, H=512, U=512, V=10000, T=20,
+                               precision="fp32", loop="searcher"),
     "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
                              precision="fp32"),
 }
@@ -72,6 +76,8 @@ def cpu_baseline(cfg, budget_s=12.0):
         threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     Bs = 32
     cell = cfg.get("cell", "lstm")
+    if cfg.get("loop") == "searcher":
+        return cpu_baseline_searcher(cfg, budget_s)
     p = co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"])
     if cell == "gru":
         p = co.add_gru_params(p, 0)
@@ -96,6 +102,30 @@ def cpu_baseline(cfg, budget_s=12.0):
             "hoisted_note": "same oracle with the step-invariant W1(features) computed once per "
                             "decode, so that the ratio is not inflated by that inefficiency of "
                             "the reference loop"}
+
+
+def cpu_baseline_searcher(cfg, budget_s):
+    """The oracle's restatement of the searcher loop on B=32 encoded feature maps."""
+    from oracle import caption_oracle as co
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    Bs = 32
+    p = co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"])
+    feats = co.mlp_encoder(co.make_images(1, Bs, cfg["L"], cfg["F"]), p["enc_kernel"], p["enc_bias"])
+    seqs = np.zeros((Bs, cfg["T"] + 1), np.int32)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        co.baseline_sequence_beam_search(p, feats, seqs, cfg["W"], cfg["V"], cfg["T"] + 1, 3, 4, 0)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 50:
+            break
+    return {"value": round(Bs * reps / el, 2), "unit": "captions/s", "cores": threads, "kind": "port",
+            "sample": "%d searches of B=%d feature maps (beam %d, %d steps, V=%d), numpy oracle, %.1f s"
+                      % (reps, Bs, cfg["W"], cfg["T"], cfg["V"], el)}
 
 
 def main():
@@ -126,6 +156,7 @@ def main():
 
     cfg = dict(CONFIGS[args.config])
     precision = cfg.pop("precision")
+    loop = cfg.pop("loop", "decode")
     p = synthetic.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"], cfg["U"])
     if cfg.get("cell") == "gru":
         p = synthetic.add_gru_params(p, 0)
@@ -136,8 +167,17 @@ def main():
     tokens = torch.empty(cfg["B"], cfg["T"], dtype=torch.int32, device=device)
     scores = torch.empty(cfg["B"], dtype=torch.float32, device=device)
 
+    feats = None
+    if loop == "searcher":      # the searcher starts from encoded features [B,L,D], resident in HBM
+        from image_caption_amd import ops
+        feats = ops.dense(img.reshape(-1, cfg["F"]), eng.weights["enc_kernel"], eng.weights["enc_bias"],
+                          act=ops.ACT_RELU).reshape(cfg["B"], cfg["L"], cfg["D"]).contiguous()
+
     def step():
-        eng.decode(img, out=tokens, scores=scores)
+        if loop == "searcher":
+            eng.search_baseline(feats, out=tokens, scores=scores)
+        else:
+            eng.decode(img, out=tokens, scores=scores)
         if world > 1:
             return all_gather_sequences(tokens)
         return tokens
@@ -248,7 +288,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(dict(cfg, loop=loop))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -90,6 +90,8 @@ SIGNATURES = {
     "icap_engine_refresh_weights": ([_P, _P], C.c_int),
     "icap_engine_workspace_bytes": ([_P], C.c_size_t),
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
+    "icap_search_baseline": ([_P, _P, _P, _I, _P, _P, _P], C.c_int),
+    "icap_logit_masks_f32": ([_P, _I, _I, _I, _P, _I, _I, _I, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
     "icap_engine_set_overlap": ([_P, _I], C.c_int),

@@ -8,11 +8,16 @@
 //                      word / parent split, log-prob gather, finished and length update.
 //   mask_probs_f32, length_penalty_f32, hyp_score_f32, batch_gather_f32
 //                      the stand-alone helpers of beam_search.py:115-141,165-197,347-358.
+//   logit_masks_f32    the additive start / forced-eos / forced-pad logit masks of the
+//                      baseline beam searcher (utils/agent_utils.py:188-237), in place.
+//   expand_rows_i32    per-image int32 values to beam rows (tf.tile of the target lengths,
+//                      utils/agent_utils.py:183-184).
 //
 // All of it is streaming element-wise work: one 16-byte access per lane where the row
 // layout allows it, two reads of a logit row at most (the second one is L2-hot).
 #include "beam_shared.h"
 #include "icap_common.h"
+#include "topk_epilogue.h"
 
 namespace icap {
 namespace {
@@ -170,7 +175,70 @@ __global__ __launch_bounds__(NT) void batch_gather_kernel(const float* __restric
   out[o] = a[(size_t)b * X + j];
 }
 
+// One thread per four consecutive logits of a row (V % 4 == 0) or per logit.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void logit_masks_kernel(float* __restrict__ logits, int N, int V,
+                                                         LogitMasks mk) {
+  constexpr int E = VEC ? 4 : 1;
+  const long long per_row = V / E;
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i >= per_row * N) return;
+  const int row = (int)(i / per_row);
+  const int c0 = (int)(i - row * per_row) * E;
+  float* q = logits + (size_t)row * V + c0;
+  float x[E];
+  if constexpr (VEC) {
+    const float4 v = *reinterpret_cast<const float4*>(q);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+    x[0] = *q;
+  }
+  apply_logit_masks<E>(x, c0, row, N, mk);
+  if constexpr (VEC)
+    *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]);
+  else
+    *q = x[0];
+}
+
+__global__ __launch_bounds__(NT) void expand_rows_i32_kernel(const int32_t* __restrict__ src,
+                                                             int32_t* __restrict__ dst, int B, int W,
+                                                             int tile_mode) {
+  const int n = blockIdx.x * NT + threadIdx.x;
+  if (n >= B * W) return;
+  dst[n] = src[tile_mode == ICAP_TILE_REPEAT ? n / W : n % B];
+}
+
 }  // namespace
+
+int logit_masks_f32(float* logits, int N, int V, const LogitMasks& mk, hipStream_t s) {
+  ICAP_REQUIRE(logits, "logit_masks_f32: null pointer");
+  ICAP_REQUIRE(N > 0 && V > 0, "logit_masks_f32: bad shape");
+  ICAP_REQUIRE(mk.start_col < V && mk.eos < V && mk.pad < V, "logit_masks_f32: token outside the vocabulary");
+  ICAP_REQUIRE(!mk.row_len || (mk.eos >= 0 && mk.pad >= 0),
+               "logit_masks_f32: eos and pad tokens are required with row lengths");
+  if (!mk.any()) return ICAP_OK;
+  const bool vec = (V % 4 == 0) && aligned16(logits);
+  const long long threads = (long long)N * (vec ? V / 4 : V);
+  ICAP_REQUIRE(threads / NT < (1LL << 31), "logit_masks_f32: too many elements");
+  const dim3 grid((unsigned)((threads + NT - 1) / NT));
+  if (vec)
+    hipLaunchKernelGGL(logit_masks_kernel<true>, grid, dim3(NT), 0, s, logits, N, V, mk);
+  else
+    hipLaunchKernelGGL(logit_masks_kernel<false>, grid, dim3(NT), 0, s, logits, N, V, mk);
+  ICAP_LAUNCH_CHECK("logit_masks_kernel");
+  return ICAP_OK;
+}
+
+int expand_rows_i32(const int32_t* src, int32_t* dst, int B, int W, int tile_mode, hipStream_t s) {
+  ICAP_REQUIRE(src && dst, "expand_rows_i32: null pointer");
+  ICAP_REQUIRE(B > 0 && W > 0, "expand_rows_i32: bad shape");
+  ICAP_REQUIRE(tile_mode == ICAP_TILE_REFERENCE || tile_mode == ICAP_TILE_REPEAT,
+               "expand_rows_i32: unknown tile_mode %d", tile_mode);
+  hipLaunchKernelGGL(expand_rows_i32_kernel, dim3((B * W + NT - 1) / NT), dim3(NT), 0, s, src, dst, B,
+                     W, tile_mode);
+  ICAP_LAUNCH_CHECK("expand_rows_i32_kernel");
+  return ICAP_OK;
+}
 
 int beam_scores_f32(const float* logits, const float* log_probs, const uint8_t* finished,
                     const int32_t* lengths, int eos_token, double length_penalty_weight,

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "icap_common.h"
+#include "topk_epilogue.h"
 
 namespace icap {
 
@@ -45,19 +46,21 @@ int dense_topk_half_tiles(int N);
 int dense_topk_record_floats(int top_k);
 bool dense_topk_supported(const float*, const float*, int, int, int, int);
 int dense_topk_f32(const float*, const float*, const float*, int, int, int, int, int, float*, float*,
-                   hipStream_t);
+                   const LogitMasks*, hipStream_t);
+int logit_masks_f32(float*, int, int, const LogitMasks&, hipStream_t);
+int expand_rows_i32(const int32_t*, int32_t*, int, int, int, hipStream_t);
 bool beam_records_supported(int W, int half_tiles, int top_k);
 size_t packed_split_bytes(int K, int N);
 int pack_weight_split(const float*, void*, int, int, int, int, int, hipStream_t);
 int dense_split(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
 bool dense_topk_split_supported(const float*, int, int, int, int);
 int dense_topk_split(const float*, const void*, const float*, int, int, int, int, int, float*,
-                     float*, hipStream_t);
+                     float*, const LogitMasks*, hipStream_t);
 int lstm_step_split(const float*, const float*, const float*, const void*, const float*,
                     const float*, const int32_t*, float*, float*, int, int, int, int, hipStream_t);
 bool dense_topk_bf16_supported(const float*, int, int, int, int);
 int dense_topk_bf16(const float*, const void*, const float*, int, int, int, int, int, float*, float*,
-                    hipStream_t);
+                    const LogitMasks*, hipStream_t);
 int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
                                const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
                                uint8_t*, int32_t*, int, int, int, hipStream_t);
@@ -102,6 +105,7 @@ struct icap_engine {
   float *h[2], *c, *q, *ctx, *fc1o, *logits;
   float *lp, *hist_scores, *hist_lp;
   int32_t *len, *hist_ids, *hist_parents, *start_ids;
+  int32_t* row_len = nullptr;  // [N] target length of every beam row (baseline searcher)
   uint8_t* fin;
   char* beam_ws;
   size_t beam_ws_bytes;
@@ -216,27 +220,48 @@ int engine_dense(const icap_engine* e, int which, const float* x, const float* w
   return dense_f32(x, wf, bias, y, M, K, N, act, s);
 }
 
+// The loop variants: the decode loop of recurrent_example.py:477-562 (all defaults) and the
+// baseline beam searcher of utils/agent_utils.py:152-262, which starts from encoded features,
+// counts beam-search time from 1 (so the first step already ranks all W rows), masks the
+// start token at every step and, with target lengths, forces eos / pad by position.
+struct LoopVariant {
+  const float* features = nullptr;  // encoded [B,L,D]: skips the encoder
+  const int32_t* seq_len = nullptr; // [B] target lengths (null: no forced eos / pad)
+  int time_offset = 0;
+  int mask_start = 0;
+  int pad = 0;
+};
+
 int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_score,
-                hipStream_t s) {
+                hipStream_t s, const LoopVariant& lv = LoopVariant()) {
   const icap_config& c = e->cfg;
   const icap_weights& w = e->w;
   const int N = c.B * c.W;
   const int BL = c.B * c.L;
   const bool gru = c.cell == ICAP_CELL_GRU;
 
-  {  // K0: features = relu(img . Wenc + benc)
+  const float* features = lv.features ? lv.features : e->features;
+  if (!lv.features) {  // K0: features = relu(img . Wenc + benc)
     Timed t(e, ICAP_K_ENCODE, s);
     ICAP_TRY(engine_dense(e, icap_engine::PK_ENC, img, w.enc_kernel, w.enc_bias, e->features, BL,
                           c.F, c.D, ICAP_ACT_RELU, s));
   }
   {  // K1: PF = features . W1 + b1   (step invariant, per image)
     Timed t(e, ICAP_K_FEAT_PROJ, s);
-    ICAP_TRY(engine_dense(e, icap_engine::PK_W1, e->features, w.att_w1_kernel, w.att_w1_bias, e->pf,
+    ICAP_TRY(engine_dense(e, icap_engine::PK_W1, features, w.att_w1_kernel, w.att_w1_bias, e->pf,
                           BL, c.D, c.U, ICAP_ACT_NONE, s));
+  }
+  LogitMasks masks;
+  if (lv.mask_start) masks.start_col = c.start_id;
+  if (lv.seq_len) {
+    ICAP_TRY(expand_rows_i32(lv.seq_len, e->row_len, c.B, c.W, c.tile_mode, s));
+    masks.row_len = e->row_len;
+    masks.eos = c.eos_id;
+    masks.pad = lv.pad;
   }
   {  // K2: h0, c0 per image, expanded to the beam rows
     Timed t(e, ICAP_K_INIT_STATE, s);
-    ICAP_TRY(pool_features_f32(e->features, nullptr, e->pooled, c.B, c.L, c.D, s));
+    ICAP_TRY(pool_features_f32(features, nullptr, e->pooled, c.B, c.L, c.D, s));
     ICAP_TRY(engine_dense(e, icap_engine::PK_INIT_H, e->pooled, w.init_h_kernel, w.init_h_bias,
                           e->init_h, c.B, c.D, c.H, ICAP_ACT_NONE, s));
     ICAP_TRY(expand_rows_f32(e->init_h, e->h[0], c.B, c.W, c.H, c.reset_state_from_feat,
@@ -273,7 +298,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     }
     {  // K5: additive attention + beta gate
       Timed tm(e, ICAP_K_ATTENTION, st);
-      ICAP_TRY(attention_f32(e->pf, e->features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
+      ICAP_TRY(attention_f32(e->pf, features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
                              state, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
                              stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st));
     }
@@ -315,24 +340,28 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                             c.H, c.H, ICAP_ACT_NONE, s));
     }
     const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
+    const int bs_time = t + lv.time_offset;  // the beam step ranks beam 0 only at time 0
+    masks.step1 = bs_time + 1;
+    const LogitMasks* mk = masks.any() ? &masks : nullptr;
     if (e->topk) {
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
       {
         Timed tm(e, ICAP_K_VOCAB, s);
         if (c.precision == ICAP_PRECISION_BF16)
           ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
-                                   c.eos_id, e->topk, e->rec, e->eos_x, s));
+                                   c.eos_id, e->topk, e->rec, e->eos_x, mk, s));
         else if (c.precision == ICAP_PRECISION_F32_SPLIT)
           ICAP_TRY(dense_topk_split(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
-                                    c.eos_id, e->topk, e->rec, e->eos_x, s));
+                                    c.eos_id, e->topk, e->rec, e->eos_x, mk, s));
         else
           ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
-                                  e->topk, e->rec, e->eos_x, s));
+                                  e->topk, e->rec, e->eos_x, mk, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
       Timed tm(e, ICAP_K_BEAM, s);
       ICAP_TRY(beam_step_from_records_f32(
-          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, t, c.eos_id,
+          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, bs_time,
+          c.eos_id,
           c.length_penalty_weight, e->hist_scores + (size_t)t * N, e->hist_ids + (size_t)t * N,
           e->hist_parents + (size_t)t * N, e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W,
           c.V, s));
@@ -342,12 +371,13 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       Timed tm(e, ICAP_K_VOCAB, s);
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
                             c.H, c.V, ICAP_ACT_NONE, s));
+      if (mk) ICAP_TRY(logit_masks_f32(e->logits, N, c.V, masks, s));
     }
     if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
     {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
        // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
-      ICAP_TRY(beam_step_f32(e->logits, lp_in, e->fin, e->len, t, 0, c.eos_id,
+      ICAP_TRY(beam_step_f32(e->logits, lp_in, e->fin, e->len, bs_time, 0, c.eos_id,
                              c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
                              e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
                              e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W, c.V,
@@ -369,7 +399,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 105; }
+int icap_version(void) { return 106; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -420,7 +450,7 @@ int icap_dense_split(const float* x, const void* packed_w, const float* bias, fl
 int icap_dense_topk_split(const float* x, const void* packed_w, const float* bias, int M, int K,
                           int N, int eos_token, int top_k, float* records, float* eos_logit,
                           icap_stream_t stream) {
-  return dense_topk_split(x, packed_w, bias, M, K, N, eos_token, top_k, records, eos_logit,
+  return dense_topk_split(x, packed_w, bias, M, K, N, eos_token, top_k, records, eos_logit, nullptr,
                           (hipStream_t)stream);
 }
 
@@ -532,7 +562,7 @@ int icap_dense_topk_record_floats(int top_k) { return dense_topk_record_floats(t
 int icap_dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K, int N,
                         int eos_token, int top_k, float* records, float* eos_logit,
                         icap_stream_t stream) {
-  return dense_topk_f32(x, w, bias, M, K, N, eos_token, top_k, records, eos_logit,
+  return dense_topk_f32(x, w, bias, M, K, N, eos_token, top_k, records, eos_logit, nullptr,
                         (hipStream_t)stream);
 }
 
@@ -587,6 +617,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_hp = cv.take<int32_t>(TN), o_si = cv.take<int32_t>(N), o_fin = cv.take<uint8_t>(N),
                o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
+  const size_t o_rl = cv.take<int32_t>(N);
   const bool gru = c.cell == ICAP_CELL_GRU;
   const size_t o_gk = cv.take<float>(gru ? (size_t)(c.D + c.E) * 4 * c.H : 0),
                o_gr = cv.take<float>(gru ? (size_t)c.H * 4 * c.H : 0),
@@ -674,6 +705,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws = b + o_bws;
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
+  e->row_len = (int32_t*)(b + o_rl);
   if (gru) {
     e->gru_k4 = (float*)(b + o_gk);
     e->gru_r4 = (float*)(b + o_gr);
@@ -754,6 +786,32 @@ int icap_decode(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   ICAP_REQUIRE(e && img && tokens, "icap_decode: null argument");
   if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;  // bound the event pool
   return decode_impl(e, img, tokens, best_score, (hipStream_t)stream);
+}
+
+int icap_search_baseline(icap_engine* e, const float* features, const int32_t* seq_len,
+                         int pad_token, int32_t* tokens, float* best_score, icap_stream_t stream) {
+  ICAP_REQUIRE(e && features && tokens, "icap_search_baseline: null argument");
+  ICAP_REQUIRE(pad_token >= 0 && pad_token < e->cfg.V,
+               "icap_search_baseline: pad token outside the vocabulary");
+  if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;
+  LoopVariant lv;
+  lv.features = features;
+  lv.seq_len = seq_len;
+  lv.time_offset = 1;
+  lv.mask_start = 1;
+  lv.pad = pad_token;
+  return decode_impl(e, nullptr, tokens, best_score, (hipStream_t)stream, lv);
+}
+
+int icap_logit_masks_f32(float* logits, int N, int V, int start_token, const int32_t* row_len,
+                         int step_plus_1, int eos_token, int pad_token, icap_stream_t stream) {
+  LogitMasks mk;
+  mk.start_col = start_token;
+  mk.row_len = row_len;
+  mk.step1 = step_plus_1;
+  mk.eos = eos_token;
+  mk.pad = pad_token;
+  return logit_masks_f32(logits, N, V, mk, (hipStream_t)stream);
 }
 
 int icap_engine_trace(const icap_engine* e, int32_t* ids, int32_t* parents, float* scores,

@@ -46,6 +46,7 @@ struct Bf16Args {
   float* rec;
   float* eos_x;
   int eos;
+  LogitMasks masks;  // additive masks applied before the records are built (default: none)
 };
 
 template <int BM, bool LSTM, int TOPK = 0>
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
     const int row = m0 + wm * WTM + lane;
+    if (p.masks.any()) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
     const TopkRow<TOPK> rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
     if (row < p.M) {
       if (rec.has_eos) p.eos_x[row] = rec.eos_v;
@@ -317,7 +319,8 @@ bool dense_topk_bf16_supported(const float* x, int M, int K, int N, int top_k) {
 
 // icap_dense_topk_f32 with bf16 operands: same records (see include/icap.h), packed weights.
 int dense_topk_bf16(const float* x, const void* packed_w, const float* bias, int M, int K, int N,
-                    int eos, int top_k, float* records, float* eos_logit, hipStream_t s) {
+                    int eos, int top_k, float* records, float* eos_logit, const LogitMasks* masks,
+                     hipStream_t s) {
   ICAP_REQUIRE(x && packed_w && records && eos_logit, "dense_topk_bf16: null pointer");
   ICAP_REQUIRE(dense_topk_bf16_supported(x, M, K, N, top_k),
                "dense_topk_bf16: needs top_k in {1,3,5}, K %% 64 == 0 and a 16-byte aligned x "
@@ -328,6 +331,7 @@ int dense_topk_bf16(const float* x, const void* packed_w, const float* bias, int
   a.w = static_cast<const uint16_t*>(packed_w);
   a.bias = bias; a.y = nullptr; a.M = M; a.N = N; a.K = K; a.act = ICAP_ACT_NONE;
   a.rec = records; a.eos_x = eos_logit; a.eos = eos;
+  if (masks) a.masks = *masks;
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, BN);
   const dim3 grid(a.tiles_m * a.tiles_n), block(256);

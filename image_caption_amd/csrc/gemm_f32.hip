@@ -40,6 +40,7 @@ struct DenseArgs {
   float* rec;    // [M][2*tiles_n][2 + 2*WL]: max, sum exp(x - max), WL best x, WL columns
   float* eos_x;  // [M]: the logit of column `eos`
   int eos;
+  LogitMasks masks;  // additive masks applied before the records are built (default: none)
 };
 
 // Guarded 4-float load without control flow: the address is clamped to `safe` (any
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       const float4 v = *reinterpret_cast<const float4*>(patch + lr * T_LD + part * 32 + 4 * q);
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
+    if (p.masks.any()) apply_logit_masks<32>(x, cbase, row, p.M, p.masks);
     TopkRow<TOPK> rec = topk_scan<TOPK, 32>(x, cbase, p.eos);
     if (rec.has_eos && row < p.M) p.eos_x[row] = rec.eos_v;
     // 3. the two lanes of a row meet (neighbour swap inside each quad)
@@ -1118,13 +1120,15 @@ bool dense_topk_supported(const float* x, const float* w, int M, int K, int N, i
 }
 
 int dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K, int N,
-                   int eos, int top_k, float* records, float* eos_logit, hipStream_t s) {
+                   int eos, int top_k, float* records, float* eos_logit, const LogitMasks* masks,
+                   hipStream_t s) {
   ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_f32: null pointer");
   ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k),
                "dense_topk_f32: needs top_k in {1,3,5}, K %% 32 == 0, N %% 4 == 0 and 16-byte "
                "aligned operands (M=%d K=%d N=%d top_k=%d)", M, K, N, top_k);
   ICAP_REQUIRE(aligned16(records), "dense_topk_f32: records must be 16-byte aligned");
   DenseArgs a{x, w, bias, nullptr, M, N, K, K, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  if (masks) a.masks = *masks;
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, 128);
   a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;

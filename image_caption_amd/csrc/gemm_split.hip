@@ -55,6 +55,7 @@ struct SplitArgs {
   float* rec;
   float* eos_x;
   int eos;
+  LogitMasks masks;  // additive masks applied before the records are built (default: none)
 };
 
 // x = hi + mid + lo exactly (round-to-nearest-even conversions; the differences are exact)
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitArgs p) {
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
     const int row = m0 + wm * WTM + lane;
+    if (p.masks.any()) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
     const TopkRow<TOPK> rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
     if (row < p.M) {
       if (rec.has_eos) p.eos_x[row] = rec.eos_v;
@@ -387,7 +389,8 @@ bool dense_topk_split_supported(const float* x, int M, int K, int N, int top_k) 
 }
 
 int dense_topk_split(const float* x, const void* packed_w, const float* bias, int M, int K, int N,
-                     int eos, int top_k, float* records, float* eos_logit, hipStream_t s) {
+                     int eos, int top_k, float* records, float* eos_logit, const LogitMasks* masks,
+                     hipStream_t s) {
   ICAP_REQUIRE(x && packed_w && records && eos_logit, "dense_topk_split: null pointer");
   ICAP_REQUIRE(dense_topk_split_supported(x, M, K, N, top_k),
                "dense_topk_split: needs top_k in {1,3,5}, K %% 32 == 0 and a 16-byte aligned x "
@@ -396,6 +399,7 @@ int dense_topk_split(const float* x, const void* packed_w, const float* bias, in
   SplitArgs a = {};
   fill_dense(a, x, packed_w, bias, M, K, N);
   a.rec = records; a.eos_x = eos_logit; a.eos = eos;
+  if (masks) a.masks = *masks;
   if (top_k == 1) return launch<128, false, 1>(a, s, "gemm_split_kernel<topk>");
   if (top_k == 3) return launch<128, false, 3>(a, s, "gemm_split_kernel<topk>");
   return launch<128, false, 5>(a, s, "gemm_split_kernel<topk>");

@@ -11,6 +11,19 @@ namespace icap {
 
 constexpr int TOPK_EMPTY = 0x7fffffff;
 
+// Additive logit masks of the baseline beam searcher (utils/agent_utils.py:188-237), applied
+// to the logits of a row before the log-softmax: float32.min on the start token's column at
+// every step; with per-row target lengths, float32.min on every column but `eos` at the step
+// where step1 == row_len[row], and on every column but `pad` where step1 > row_len[row].
+// Disabled (the decode loop of recurrent_example.py) when start_col < 0 and row_len is null.
+struct LogitMasks {
+  int start_col = -1;
+  const int32_t* row_len = nullptr;
+  int step1 = 0;  // the searcher's loop index i plus one
+  int eos = -1, pad = -1;
+  __host__ __device__ bool any() const { return start_col >= 0 || row_len != nullptr; }
+};
+
 #if defined(__HIPCC__)
 template <int TOPK>
 struct TopkRow {
@@ -21,6 +34,27 @@ struct TopkRow {
   float eos_v;      // the logit of column `eos` if it is among the scanned columns
   bool has_eos;
 };
+
+// x[e] is the logit of column cbase + e of row `row`: adds the masks in the reference's
+// order (start, then eos, then pad; two hits overflow to -inf as they do there).
+template <int NX>
+__device__ __forceinline__ void apply_logit_masks(float (&x)[NX], int cbase, int row, int n_rows,
+                                                  const LogitMasks& mk) {
+  constexpr float FMIN = -3.4028234663852886e38f;  // tf.float32.min
+  int keep = -1;  // the one column that stays unmasked in a forced row
+  if (mk.row_len != nullptr && row < n_rows) {
+    const int len = mk.row_len[row];
+    keep = mk.step1 == len ? mk.eos : (mk.step1 > len ? mk.pad : -1);
+  }
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    const int c = cbase + e;
+    float v = x[e];
+    v = (c == mk.start_col) ? v + FMIN : v;
+    v = (keep >= 0 && c != keep) ? v + FMIN : v;
+    x[e] = v;
+  }
+}
 
 // x[e] is the logit of column cbase + e; invalid columns must hold -inf.
 template <int TOPK, int NX>

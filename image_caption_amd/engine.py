@@ -154,6 +154,25 @@ class CaptionEngine:
                   ops.current_stream())
         return out, scores
 
+    def search_baseline(self, features, seq_len=None, pad_token=0, out=None, scores=None):
+        """The baseline beam searcher's loop (reference utils/agent_utils.py:152-262) on
+        encoded features [B,L,D]: returns (tokens [B,T] int32 without the start column,
+        scores [B]).  seq_len [B] int32: target lengths for the forced eos / pad masks."""
+        c = self.config
+        if tuple(features.shape) != (c.B, c.L, c.D):
+            raise ValueError("features must have shape %s" % ((c.B, c.L, c.D),))
+        if out is None:
+            out = torch.empty(c.B, c.T, dtype=torch.int32, device=self.device)
+        if scores is None:
+            scores = torch.empty(c.B, dtype=torch.float32, device=self.device)
+        if seq_len is not None and tuple(seq_len.shape) != (c.B,):
+            raise ValueError("seq_len must have shape (%d,)" % c.B)
+        _lib.call("icap_search_baseline", self._handle, ops._chk(features, torch.float32, "features"),
+                  ops._opt(seq_len, torch.int32, "seq_len"), int(pad_token),
+                  ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
+                  ops.current_stream())
+        return out, scores
+
     def trace(self):
         """Per-step records of the last decode as tensors [T,B,W]: ids, parents (int32),
         scores, log_probs (float32)."""

@@ -166,6 +166,18 @@ def gru_step(ctx, h, kernel4, recurrent4, bias4, emb=None, table=None, ids=None,
     return h_out
 
 
+def logit_masks(logits, start_token=-1, row_len=None, step_plus_1=0, eos_token=-1, pad_token=-1):
+    """The baseline searcher's additive masks on logits [N,V], in place (returns logits):
+    float32.min on column start_token; with row_len [N] int32, on all columns but eos_token
+    where step_plus_1 == row_len[n] and on all but pad_token where step_plus_1 > row_len[n]."""
+    V = logits.shape[-1]
+    N = logits.numel() // V
+    _lib.call("icap_logit_masks_f32", _chk(logits, f32, "logits"), N, V, int(start_token),
+              _opt(row_len, i32, "row_len"), int(step_plus_1), int(eos_token), int(pad_token),
+              current_stream())
+    return logits
+
+
 _beam_ws = {}
 
 

@@ -336,6 +336,28 @@ size_t icap_engine_workspace_bytes(const icap_engine* engine);
 int icap_decode(icap_engine* engine, const float* img, int32_t* tokens,
                 float* best_score, icap_stream_t stream);
 
+/* The loop of the baseline beam searcher (SCST / actor-critic baselines) on the same engine:
+ *   features[B,L,D] f32 (already encoded) -> tokens[B,T] i32, T = cfg.T = max_length - 1
+ * tile -> reset_state -> for i = 1..T: decoder step, logits += start-token mask, with
+ * seq_len also the forced-eos mask where i+1 == seq_len[image] and the forced-pad mask where
+ * i+1 > seq_len[image], beam step at time i (never the time-0 form, so the first step
+ * already ranks all W rows) -> back-track.  seq_len[B] i32 = number of non-pad tokens of the
+ * target sequences (NULL: the max_length > 0 form without forced tokens); the caller
+ * prepends the start-token column.  length_penalty_weight comes from the engine's config
+ * (the searcher uses 1.0).  Replaces BaselineSequeneBeamSearcher.__call__,
+ * utils/agent_utils.py:152-262. */
+int icap_search_baseline(icap_engine* engine, const float* features, const int32_t* seq_len,
+                         int pad_token, int32_t* tokens, float* best_score,
+                         icap_stream_t stream);
+
+/* The searcher's additive masks on a logits buffer [N,V], in place: float32.min on column
+ * start_token (< 0: none); with row_len[N] (may be NULL) float32.min on every column but
+ * eos_token where step_plus_1 == row_len[n], on every column but pad_token where
+ * step_plus_1 > row_len[n].  Replaces utils/agent_utils.py:188-237 (and the three masks
+ * of SequenceSampler, :81-107, with start = each of pad/start/eos in turn). */
+int icap_logit_masks_f32(float* logits, int N, int V, int start_token, const int32_t* row_len,
+                         int step_plus_1, int eos_token, int pad_token, icap_stream_t stream);
+
 /* Copies the per-step records of the last icap_decode into caller buffers (device
  * pointers, any may be NULL): ids, parents [T,B,W] i32; scores, log_probs [T,B,W] f32
  * (BeamSearchStepOutput / BeamSearchState.log_probs of every step).  Enqueued on

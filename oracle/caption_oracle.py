@@ -461,6 +461,67 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     return tokens
 
 
+def sequence_length_fn(sequences, sequence_mask, keepdims=False):
+    """`utils/agent_utils.py:30-32`: number of tokens greater than the pad token."""
+    flag = (np.asarray(sequences) > sequence_mask).astype(np.int32)
+    return np.sum(flag, axis=-1, keepdims=keepdims)
+
+
+def baseline_sequence_beam_search(p, features, sequences, beam_width, vocab_size, max_length,
+                                  start_token, eos_token, pad_token=0, cell="lstm",
+                                  reset_state_from_feat=1, return_trace=False):
+    """`BaselineSequeneBeamSearcher.__call__` (`utils/agent_utils.py:152-262`) over
+    `RnnDecoderNetwork(decoder)` (`utils/reinforce.py:75-85`).
+
+    features [B,L,D] are already encoded; tf.tile layout (row r -> image r % B, `:162`,
+    lengths tiled the same way `:184`) while the logits are read as row = image*W + beam
+    (`:239-240`).  Loop index i runs 1..max_length-1 and is the beam step's time, so the
+    time-0 form never runs.  s_mask is float32.min at the start token (`:188-193`); with
+    max_length <= 0 (length taken from `sequences`) e_mask / p_mask are float32.min
+    everywhere but eos / pad and are added where i+1 == length / i+1 > length
+    (`:195-237`).  length_penalty_weight is 1.0 (`:172`).  The state is not reordered
+    (`:218-221`).  Returns int32 [B, steps+1] with the start token in column 0 (`:257-260`)."""
+    step_fn = lstm_decoder_step if cell == "lstm" else gru_decoder_step
+    reset_fn = reset_state if cell == "lstm" else reset_state_gru
+    B, W, V = features.shape[0], beam_width, vocab_size
+    fmin = np.float32(np.finfo(np.float32).min)
+    dec_input = np.full([B * W, 1], start_token, np.int32)
+    feats = np.tile(features, (W, 1, 1))
+    hidden = reset_fn(p, B * W, feats, reset_state_from_feat)
+    state = create_initial_beam_state_batch(B, W, dtype=features.dtype)
+    config = BeamSearchConfig(W, V, eos_token, 1.0, choose_top_k)
+    forced = max_length <= 0
+    if forced:
+        max_length = np.asarray(sequences).shape[1]
+    seq_len = np.tile(sequence_length_fn(sequences, pad_token, keepdims=True), (W, 1))  # [B*W,1]
+    s_mask = np.zeros((1, V), np.float32)
+    s_mask[0, start_token] = fmin
+    e_mask = np.full((1, V), fmin, np.float32)
+    e_mask[0, eos_token] = 0.0
+    p_mask = np.full((1, V), fmin, np.float32)
+    p_mask[0, pad_token] = 0.0
+    seq, trace = [], []
+    with np.errstate(over="ignore", invalid="ignore"):
+        for i in range(1, max_length):
+            logits, hidden, _, _ = step_fn(p, dec_input, feats, hidden)
+            logits = logits + s_mask
+            if forced:
+                logits = logits + e_mask * (i + 1 == seq_len).astype(np.float32)
+                logits = logits + p_mask * (i + 1 > seq_len).astype(np.float32)
+            logits3 = logits.reshape(-1, W, V)
+            out, state = beam_search_step_batch(i, logits3, state, config)
+            seq.append((out, state))
+            if return_trace:
+                trace.append({"logits": logits3, "out": out, "state": state})
+            dec_input = out.predicted_ids.reshape(-1, 1)
+    path = loc_optimal_beam_path_batch(seq)
+    tokens = np.concatenate(path, axis=1).astype(np.int32)
+    tokens = np.concatenate([np.full((B, 1), start_token, np.int32), tokens], axis=1)
+    if return_trace:
+        return tokens, trace
+    return tokens
+
+
 # ----------------------------------------------------------------------------------
 # synthetic weights / inputs (Keras default initialisers)
 # ----------------------------------------------------------------------------------

@@ -1,0 +1,182 @@
+"""BaselineSequeneBeamSearcher / SequenceBeamSearchSampler (reference
+utils/agent_utils.py:134-284) vs the oracle's restatement of that loop.
+
+No reference test or fixture covers the searcher: parity unpinned.  In its target-length
+form the reference itself forms NaN candidates (a finished beam in a forced row: 0 * -inf at
+the doubly masked start column inside mask_probs); a comparison-based top-k never ranks them
+above the W finite candidates that always exist, the oracle sorts them last and the engine
+never forms them.  Token ids must be identical to the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caption_oracle as co
+from tests.helpers import dev, np_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(F=24, D=8, E=8, H=12, V=37)
+FMIN = np.float32(np.finfo(np.float32).min)
+
+
+def _params(seed, dims, cell, bias_seed=None):
+    p = co.make_params(seed, **dims)
+    if cell == "gru":
+        p = co.add_gru_params(p, seed)
+    return co.perturb_biases(p, bias_seed) if bias_seed is not None else p
+
+
+def _sequences(rng, B, T, pad=0):
+    """Targets [B,T]: start, words, eos, then padding; lengths between 3 and T."""
+    seq = np.full((B, T), pad, np.int32)
+    for b in range(B):
+        n = int(rng.integers(3, T + 1))
+        seq[b, 0] = 3
+        seq[b, 1:n - 1] = rng.integers(5, 30, size=n - 2)
+        seq[b, n - 1] = 4
+    return seq
+
+
+@pytest.mark.parametrize("N,V", [(7, 37), (12, 40), (1536, 10000)])
+def test_logit_masks(N, V):
+    from image_caption_amd import ops
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((N, V)).astype(np.float32) * 3
+    row_len = rng.integers(2, 9, size=N).astype(np.int32)
+    for step1, with_len in ((5, False), (5, True), (2, True), (9, True)):
+        ref = x.copy()
+        ref[:, 3] += FMIN
+        if with_len:
+            with np.errstate(over="ignore"):
+                e = np.full(V, FMIN, np.float32); e[4] = 0
+                pd = np.full(V, FMIN, np.float32); pd[0] = 0
+                ref = ref + e[None] * (step1 == row_len)[:, None].astype(np.float32)
+                ref = ref + pd[None] * (step1 > row_len)[:, None].astype(np.float32)
+        t = to_dev(x.copy())
+        ops.logit_masks(t, start_token=3, row_len=to_dev(row_len) if with_len else None,
+                        step_plus_1=step1, eos_token=4, pad_token=0)
+        np.testing.assert_array_equal(np_of(t), ref)
+    t = to_dev(x.copy())
+    ops.logit_masks(t)                       # no mask requested: unchanged
+    np.testing.assert_array_equal(np_of(t), x)
+
+
+def _engine_search(p, feats, seqs, W, max_length, dims, cell, fused, precision="fp32"):
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    B, L, D = feats.shape
+    forced = max_length <= 0
+    steps = (seqs.shape[1] if forced else max_length) - 1
+    q = dict(p)
+    q["enc_kernel"] = np.zeros((D, D), np.float32)          # the searcher starts from features
+    q["enc_bias"] = np.zeros(D, np.float32)
+    cfg = CaptionConfig(B=B, W=W, L=L, F=D, D=D, E=dims["E"], H=dims["H"], U=dims["H"], V=dims["V"],
+                        T=steps, start_id=3, eos_id=4, length_penalty_weight=1.0,
+                        tile_mode="reference", cell=cell, precision=precision)
+    eng = CaptionEngine(cfg, q, device=dev())
+    if not fused:
+        eng.set_fused_vocab(False)
+    assert eng.fused_vocab == fused
+    seq_len = None
+    if forced:
+        seq_len = to_dev((seqs > 0).sum(axis=1).astype(np.int32))
+    tok, _ = eng.search_baseline(to_dev(feats), seq_len=seq_len, pad_token=0)
+    tr = eng.trace()
+    eng.close()
+    return np_of(tok), tr
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("max_length", [6, 0])
+@pytest.mark.parametrize("fused", [True, False])
+def test_search_baseline_small(cell, max_length, fused):
+    dims = dict(F=24, D=8, E=8, H=32, V=40)               # H % 32 == 0, V % 4 == 0: fused path served
+    p = _params(1, dims, cell, bias_seed=2)
+    rng = np.random.default_rng(3)
+    B, L, W, T = 6, 5, 3, 9
+    feats = np.abs(rng.standard_normal((B, L, dims["D"]))).astype(np.float32)
+    seqs = _sequences(rng, B, T)
+    tok_o, trace_o = co.baseline_sequence_beam_search(p, feats, seqs, W, dims["V"], max_length, 3, 4,
+                                                      0, cell=cell, return_trace=True)
+    tok_g, tr = _engine_search(p, feats, seqs, W, max_length, dims, cell, fused)
+    assert tok_o.shape == (B, (max_length or T))
+    np.testing.assert_array_equal(tok_g, tok_o[:, 1:])
+    ids_o = np.stack([st["out"].predicted_ids for st in trace_o])
+    par_o = np.stack([st["out"].beam_parent_ids for st in trace_o])
+    np.testing.assert_array_equal(np_of(tr["ids"]), ids_o)
+    np.testing.assert_array_equal(np_of(tr["parents"]), par_o)
+    if max_length <= 0:
+        # forced tokens: eos where the step reaches the target length of the row's image
+        assert (tok_o[:, 1:] == 4).any()
+
+
+@pytest.mark.parametrize("max_length,precision", [(12, "fp32"), (0, "fp32"), (0, "fp32_split")])
+def test_search_baseline_production_dims(max_length, precision):
+    dims = dict(F=64, D=256, E=256, H=512, V=10000)
+    p = _params(0, dims, "lstm")
+    rng = np.random.default_rng(5)
+    B, L, W, T = 16, 64, 3, 12
+    feats = co.mlp_encoder(co.make_images(7, B, L, 64), p["enc_kernel"], p["enc_bias"])
+    seqs = _sequences(rng, B, T)
+    tok_o = co.baseline_sequence_beam_search(p, feats, seqs, W, dims["V"], max_length, 3, 4, 0)
+    tok_g, _ = _engine_search(p, feats, seqs, W, max_length, dims, "lstm", True, precision)
+    nbad = int((tok_g != tok_o[:, 1:]).any(axis=1).sum())
+    assert nbad <= 1, nbad           # (fp32 near-ties, as for the decode loop)
+
+
+def _searcher_modules(p, dims, cell):
+    from image_caption_amd.decoder import EmbeddingLayer, LstmDecoder, RecurrentDecoder
+    from image_caption_amd.utils.reinforce import RnnDecoderNetwork
+    emb = EmbeddingLayer(dims["V"], dims["E"], device=dev())
+    cls = LstmDecoder if cell == "lstm" else RecurrentDecoder
+    dec = cls(emb, dims["E"], dims["H"], dims["V"], reset_state_from_feat=1, device=dev())
+    dec.load_params(p, dev())
+    return RnnDecoderNetwork(dec)
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("max_length", [5, 0])
+def test_searcher_class_fused_and_operator_loop(cell, max_length):
+    from image_caption_amd.utils.agent_utils import (BaselineSequeneBeamSearcher,
+                                                     SequenceBeamSearchSampler, sequence_length_fn)
+    dims = dict(F=24, D=8, E=8, H=32, V=40)
+    p = _params(4, dims, cell, bias_seed=5)
+    rng = np.random.default_rng(6)
+    B, L, W, T = 5, 4, 2, 8
+    feats = np.abs(rng.standard_normal((B, L, dims["D"]))).astype(np.float32)
+    seqs = _sequences(rng, B, T)
+    tok_o = co.baseline_sequence_beam_search(p, feats, seqs, W, dims["V"], max_length, 3, 4, 0,
+                                             cell=cell)
+    net = _searcher_modules(p, dims, cell)
+    np.testing.assert_array_equal(np_of(sequence_length_fn(to_dev(seqs), 0)), (seqs > 0).sum(axis=1))
+    searcher = BaselineSequeneBeamSearcher(net, W, dims["V"], max_length, 3, 4)
+    got = searcher(to_dev(feats), to_dev(seqs))
+    assert got.dtype == torch.int32
+    np.testing.assert_array_equal(np_of(got), tok_o)
+    np.testing.assert_array_equal(np_of(searcher(to_dev(feats), to_dev(seqs))), tok_o)   # cached engine
+    searcher.use_engine = False                                      # operator-level loop
+    np.testing.assert_array_equal(np_of(searcher(to_dev(feats), to_dev(seqs))), tok_o)
+    if max_length <= 0:
+        sampler = SequenceBeamSearchSampler(net, W, dims["V"], 3, 4)
+        np.testing.assert_array_equal(np_of(sampler((to_dev(feats), to_dev(seqs)))), tok_o)
+
+
+def test_searcher_with_plain_callable_network():
+    """Any actor_network with the (predictions, state) call convention runs the loop."""
+    from image_caption_amd.utils.agent_utils import BaselineSequeneBeamSearcher
+    dims = dict(F=24, D=8, E=8, H=12, V=37)
+    p = _params(8, dims, "lstm", bias_seed=9)
+    net = _searcher_modules(p, dims, "lstm")
+
+    class Plain:
+        def __call__(self, inputs, **kwargs):
+            return net(inputs, **kwargs)
+
+        def reset_state(self, seq, feat_d, **kwargs):
+            return net.reset_state(seq, feat_d, **kwargs)
+
+    rng = np.random.default_rng(10)
+    feats = np.abs(rng.standard_normal((4, 5, dims["D"]))).astype(np.float32)
+    seqs = _sequences(rng, 4, 7)
+    tok_o = co.baseline_sequence_beam_search(p, feats, seqs, 3, dims["V"], 0, 3, 4, 0)
+    got = BaselineSequeneBeamSearcher(Plain(), 3, dims["V"], 0, 3, 4)(to_dev(feats), to_dev(seqs))
+    np.testing.assert_array_equal(np_of(got), tok_o)

@@ -170,3 +170,21 @@ def test_hoisted_w1_variant_gives_the_same_tokens():
     a = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4)
     b = co.predict_image_caption_sequence(p, img, 3, 6, 3, 4, hoist_w1=True)
     np.testing.assert_array_equal(a, b)
+
+
+def test_baseline_searcher_oracle_forces_eos_at_the_target_length():
+    """One image (so the tile layout is trivial): in the target-length form the sequence
+    starts with the start token, never repeats it, and has eos at the target's eos position
+    (or earlier) and from there on; with max_length > 0 the length is max_length."""
+    p = _params(5)
+    rng = np.random.default_rng(11)
+    feats = np.abs(rng.standard_normal((1, 4, DIMS["D"]))).astype(np.float32)
+    seqs = np.array([[3, 9, 8, 7, 4, 0, 0, 0]], np.int32)          # length 5
+    tok = co.baseline_sequence_beam_search(p, feats, seqs, 2, DIMS["V"], 0, 3, 4, 0)
+    assert tok.shape == (1, 8) and tok[0, 0] == 3
+    assert (tok[0, 1:] != 3).all()
+    first_eos = int(np.argmax(tok[0] == 4))
+    assert 1 <= first_eos <= 4 and (tok[0, first_eos:] == 4).all()
+    tok5 = co.baseline_sequence_beam_search(p, feats, seqs, 2, DIMS["V"], 5, 3, 4, 0)
+    assert tok5.shape == (1, 5) and tok5[0, 0] == 3 and (tok5[0, 1:] != 3).all()
+    assert co.sequence_length_fn(seqs, 0).tolist() == [5]
