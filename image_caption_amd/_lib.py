@@ -47,6 +47,35 @@ class IcapWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in WEIGHT_FIELDS]
 
 
+TMASK_AS_WRITTEN, TMASK_CAUSAL = 0, 1
+
+TLAYER_FIELDS = ("self_ln_gamma", "self_ln_beta", "self_q_kernel", "self_q_bias", "self_k_kernel",
+                 "self_k_bias", "self_v_kernel", "self_v_bias", "self_o_kernel", "self_o_bias",
+                 "cross_ln_gamma", "cross_ln_beta", "cross_q_kernel", "cross_q_bias",
+                 "cross_k_kernel", "cross_k_bias", "cross_v_kernel", "cross_v_bias",
+                 "cross_o_kernel", "cross_o_bias", "ffn_ln_gamma", "ffn_ln_beta",
+                 "ffn_filter_kernel", "ffn_filter_bias", "ffn_output_kernel", "ffn_output_bias")
+TWEIGHT_FIELDS = ("enc_kernel", "enc_bias", "embedding", "out_ln_gamma", "out_ln_beta",
+                  "fc2_kernel", "fc2_bias")
+TK_NAMES = ("encode", "embed", "layernorm", "proj", "self_att", "cross_att", "ffn", "vocab", "beam",
+            "backtrack")
+
+
+class IcapTConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "W", "L", "F", "D", "hidden", "heads", "key_dim",
+                                         "filter", "layers", "V", "T", "start_id", "eos_id",
+                                         "tile_mode", "mask_mode", "kv_from_normed", "precision")] + [
+        ("length_penalty_weight", C.c_double)]
+
+
+class IcapTLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TLAYER_FIELDS]
+
+
+class IcapTWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TWEIGHT_FIELDS] + [("layers", C.POINTER(IcapTLayer))]
+
+
 _P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
 
 # name -> argtypes; every entry point of include/icap.h
@@ -90,6 +119,20 @@ SIGNATURES = {
     "icap_engine_refresh_weights": ([_P, _P], C.c_int),
     "icap_engine_workspace_bytes": ([_P], C.c_size_t),
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
+    "icap_position_table_f32": ([_P, _I, _I, _P], C.c_int),
+    "icap_embed_pos_f32": ([_P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_residual_layernorm_f32": ([_P, _P, _P, _P, _P, _I, _I, _F, _P], C.c_int),
+    "icap_mha_self_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_mha_cross_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_tengine_create": ([_P, _P, _P], C.c_int),
+    "icap_tengine_destroy": ([_P], C.c_int),
+    "icap_tengine_refresh_weights": ([_P, _P], C.c_int),
+    "icap_tengine_workspace_bytes": ([_P], C.c_size_t),
+    "icap_tdecode": ([_P, _P, _P, _P, _P], C.c_int),
+    "icap_tengine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
+    "icap_tengine_last_output": ([_P, _P, _P], C.c_int),
+    "icap_tengine_set_timing": ([_P, C.c_uint], C.c_int),
+    "icap_tengine_kernel_times": ([_P, _P, _P], C.c_int),
     "icap_search_baseline": ([_P, _P, _P, _I, _P, _P, _P], C.c_int),
     "icap_logit_masks_f32": ([_P, _I, _I, _I, _P, _I, _I, _I, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),

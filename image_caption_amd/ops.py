@@ -178,6 +178,56 @@ def logit_masks(logits, start_token=-1, row_len=None, step_plus_1=0, eos_token=-
     return logits
 
 
+# ---- transformer decoder path (one target position per call) --------------------------
+
+def position_table(length, hidden, device):
+    """[length, hidden] sinusoid position encoding (RelativePositionEmbedding)."""
+    t = torch.empty(length, hidden, dtype=f32, device=device)
+    _lib.call("icap_position_table_f32", t.data_ptr(), int(length), int(hidden), current_stream())
+    return t
+
+
+def embed_pos(table, ids, pos_row):
+    """table[ids] + pos_row for one target position: [N, hidden]."""
+    V, D = table.shape
+    N = ids.numel()
+    x = torch.empty(N, D, dtype=f32, device=table.device)
+    _lib.call("icap_embed_pos_f32", _chk(table, f32, "table"), _chk(ids.reshape(-1), i32, "ids"),
+              _chk(pos_row, f32, "pos_row"), x.data_ptr(), N, V, D, current_stream())
+    return x
+
+
+def residual_layernorm(x, o, gamma, beta, eps=1e-6):
+    """x += o in place (o may be None); returns LayerNorm(x) * gamma + beta."""
+    D = x.shape[-1]
+    N = x.numel() // D
+    y = torch.empty_like(x)
+    _lib.call("icap_residual_layernorm_f32", _chk(x, f32, "x"), _opt(o, f32, "o"),
+              _chk(gamma, f32, "gamma"), _chk(beta, f32, "beta"), y.data_ptr(), N, D, float(eps),
+              current_stream())
+    return y
+
+
+def mha_self_step(q, kv_cache, heads, key_dim, pos, mask_mode=0):
+    """q [N, heads*key_dim], kv_cache [Tcap, N, 2*heads*key_dim] (position `pos` already
+    written) -> combined values [N, heads*key_dim] of the newest position."""
+    N = q.shape[0]
+    out = torch.empty_like(q)
+    _lib.call("icap_mha_self_step_f32", _chk(q, f32, "q"), _chk(kv_cache, f32, "kv_cache"),
+              out.data_ptr(), N, int(heads), int(key_dim), int(pos), int(mask_mode), current_stream())
+    return out
+
+
+def mha_cross_step(q, kv, G, rows_per_group, row_stride_g, row_stride_k, heads, key_dim):
+    """q [N, heads*key_dim], kv [G, L, 2*heads*key_dim] -> combined values [N, heads*key_dim]."""
+    L = kv.shape[1]
+    out = torch.empty_like(q)
+    _lib.call("icap_mha_cross_step_f32", _chk(q, f32, "q"), _chk(kv, f32, "kv"), out.data_ptr(),
+              int(G), int(rows_per_group), int(row_stride_g), int(row_stride_k), int(L), int(heads),
+              int(key_dim), current_stream())
+    return out
+
+
 _beam_ws = {}
 
 

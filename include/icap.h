@@ -400,6 +400,123 @@ int icap_engine_fused_vocab(const icap_engine* engine);
 int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
                              int32_t* launches /*[ICAP_K_COUNT]*/);
 
+/* ---- transformer decoder path ------------------------------------------------------
+ * decoder/transform_decoder.py + attention/attention.py:160-562 + decoder/ffn_layer.py +
+ * embedding/position_embedding.py, run incrementally: one pass of the layer stack per new
+ * target position with per-row key / value caches (the reference re-runs the whole prefix
+ * every step, transform_decoder.py:177; the results per position are the same).  No driver
+ * in the reference constructs this decoder; the loop is predict_image_caption_sequence
+ * (recurrent_example.py:477-562) with the decoder swapped. */
+
+/* Self-attention mask handling.  AS_WRITTEN: the additive causal bias (0 / -1e9) is passed
+ * as `attention_mask` (transform_decoder.py:139) and goes through (1 - mask) * -1e9
+ * (attention.py:471-473): visible positions get -1e9 added to their fp32 score, hidden ones
+ * about -1e18.  CAUSAL: the conventional additive bias. */
+#define ICAP_TMASK_AS_WRITTEN 0
+#define ICAP_TMASK_CAUSAL 1
+
+/* [length, hidden] sinusoid table of RelativePositionEmbedding.call
+ * (embedding/position_embedding.py:67-102), fp32, timescales 1 .. 1e4. */
+int icap_position_table_f32(float* table, int length, int hidden, icap_stream_t stream);
+/* x[n,:] = table[ids[n],:] + pos_row[:]  (ids NULL: token 0).  Embedding + position
+ * encoding of one target position, transform_decoder.py:206-210.  D % 4 == 0. */
+int icap_embed_pos_f32(const float* table, const int32_t* ids, const float* pos_row, float* x,
+                       int N, int V, int D, icap_stream_t stream);
+/* Pre-norm wrapper arithmetic (transform_decoder.py:35,42): x += o when o != NULL (in
+ * place), then y = LayerNormalization(x) * gamma + beta over the last axis with the biased
+ * variance and epsilon `eps` (the stack uses 1e-6).  D % 4 == 0, D <= 4096. */
+int icap_residual_layernorm_f32(float* x, const float* o, const float* gamma, const float* beta,
+                                float* y, int N, int D, float eps, icap_stream_t stream);
+/* Self-attention of the newest position `pos` of every row over its cached positions
+ * 0..pos: q[N,heads*key_dim] (unscaled; 1/sqrt(key_dim) is applied to the query first,
+ * attention.py:501); kv_cache[pos'][N][2*heads*key_dim] holds keys then values of position
+ * pos' (the caller writes position `pos` before the call); out[N,heads*key_dim] is the
+ * combined value, the input of the output projection.  Replaces
+ * MultiHeadAttention._compute_attention, attention.py:476-524, for one query position.
+ * key_dim % 4 == 0 and key_dim / 8 (or / 4) a power of two. */
+int icap_mha_self_step_f32(const float* q, const float* kv_cache, float* out, int N, int heads,
+                           int key_dim, int pos, int mask_mode, icap_stream_t stream);
+/* Encoder-decoder attention of one query position per row: kv[G][L][2*heads*key_dim] holds
+ * keys then values of the L encoder outputs of image g (no mask: the stack passes
+ * attention_bias = None); rows are grouped per image as in icap_attention_f32. */
+int icap_mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int rows_per_group,
+                            int row_stride_g, int row_stride_k, int L, int heads, int key_dim,
+                            icap_stream_t stream);
+
+typedef struct icap_tconfig {
+  int32_t B, W, L, F, D;        /* images, beam width, locations, CNN feature dim, encoder dim */
+  int32_t hidden, heads, key_dim, filter, layers; /* as written: heads = hidden_size, key_dim =
+                                  * params["num_heads"] (transform_decoder.py:65-72 binds
+                                  * positionally to attention.py:259-262) */
+  int32_t V, T;
+  int32_t start_id, eos_id;
+  int32_t tile_mode;            /* ICAP_TILE_* */
+  int32_t mask_mode;            /* ICAP_TMASK_* */
+  int32_t kv_from_normed;       /* 0 as written: self-attention keys / values from the raw
+                                 * layer input, only the query from LayerNorm(x)
+                                 * (transform_decoder.py:35-38,136-140) */
+  int32_t precision;            /* ICAP_PRECISION_FP32 */
+  double length_penalty_weight;
+} icap_tconfig;
+
+typedef struct icap_tlayer { /* device pointers; EinsumDense kernels flattened to 2-D */
+  const float* self_ln_gamma;  const float* self_ln_beta;           /* [hidden] */
+  const float* self_q_kernel;  const float* self_q_bias;            /* [hidden,HD], [HD], HD = heads*key_dim */
+  const float* self_k_kernel;  const float* self_k_bias;
+  const float* self_v_kernel;  const float* self_v_bias;
+  const float* self_o_kernel;  const float* self_o_bias;            /* [HD,hidden], [hidden] */
+  const float* cross_ln_gamma; const float* cross_ln_beta;
+  const float* cross_q_kernel; const float* cross_q_bias;           /* [hidden,HD] */
+  const float* cross_k_kernel; const float* cross_k_bias;           /* [D,HD] */
+  const float* cross_v_kernel; const float* cross_v_bias;
+  const float* cross_o_kernel; const float* cross_o_bias;
+  const float* ffn_ln_gamma;   const float* ffn_ln_beta;
+  const float* ffn_filter_kernel; const float* ffn_filter_bias;     /* [hidden,filter], [filter] */
+  const float* ffn_output_kernel; const float* ffn_output_bias;     /* [filter,hidden], [hidden] */
+} icap_tlayer;
+
+typedef struct icap_tweights {
+  const float* enc_kernel; const float* enc_bias;       /* [F,D], [D] */
+  const float* embedding;                               /* [V,hidden] */
+  const float* out_ln_gamma; const float* out_ln_beta;  /* [hidden] */
+  const float* fc2_kernel; const float* fc2_bias;       /* [hidden,V], [V] */
+  const icap_tlayer* layers;                            /* host array of cfg.layers entries (copied) */
+} icap_tweights;
+
+typedef struct icap_tengine icap_tengine;
+
+int icap_tengine_create(const icap_tconfig* config, const icap_tweights* weights,
+                        icap_tengine** out);
+int icap_tengine_destroy(icap_tengine* engine);
+/* Re-packs what the engine derives from the weights (key|value kernels side by side, the
+ * position table). */
+int icap_tengine_refresh_weights(icap_tengine* engine, icap_stream_t stream);
+size_t icap_tengine_workspace_bytes(const icap_tengine* engine);
+/* img[B,L,F] -> tokens[B,T] (+ best_score[B], may be NULL): encoder -> tile -> prefix [0] ->
+ * T x (TransformDecoder.call on [prefix | token], beam step) -> back-track. */
+int icap_tdecode(icap_tengine* engine, const float* img, int32_t* tokens, float* best_score,
+                 icap_stream_t stream);
+/* Per-step beam records of the last icap_tdecode, as icap_engine_trace. */
+int icap_tengine_trace(const icap_tengine* engine, int32_t* ids, int32_t* parents, float* scores,
+                       float* log_probs, icap_stream_t stream);
+/* The stack's normalised output of the newest position, [B*W,hidden] (the fourth value
+ * TransformDecoder.decode returns, transform_decoder.py:231) of the last step. */
+int icap_tengine_last_output(const icap_tengine* engine, float* out, icap_stream_t stream);
+#define ICAP_TK_ENCODE 0     /* encoder + encoder-side keys / values of every layer */
+#define ICAP_TK_EMBED 1
+#define ICAP_TK_LAYERNORM 2
+#define ICAP_TK_PROJ 3       /* q / k|v / output projections */
+#define ICAP_TK_SELF_ATT 4
+#define ICAP_TK_CROSS_ATT 5
+#define ICAP_TK_FFN 6
+#define ICAP_TK_VOCAB 7
+#define ICAP_TK_BEAM 8
+#define ICAP_TK_BACKTRACK 9
+#define ICAP_TK_COUNT 10
+int icap_tengine_set_timing(icap_tengine* engine, unsigned class_mask);
+int icap_tengine_kernel_times(icap_tengine* engine, float* ms /*[ICAP_TK_COUNT]*/,
+                              int32_t* launches /*[ICAP_TK_COUNT]*/);
+
 #ifdef __cplusplus
 }
 #endif

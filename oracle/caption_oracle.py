@@ -32,6 +32,7 @@ reference's `tf.float32`); passing float64 weights/inputs gives a high-precision
 
 from __future__ import annotations
 
+import math
 from collections import namedtuple
 
 import numpy as np
@@ -599,3 +600,182 @@ def make_images(seed, B, L, F):
 
 def cast_params(p, dtype):
     return {k: v.astype(dtype) for k, v in p.items()}
+
+
+# ----------------------------------------------------------------------------------
+# Transformer decoder path (decoder/transform_decoder.py, attention/attention.py:160-562,
+# decoder/ffn_layer.py, embedding/position_embedding.py).  No driver in the reference
+# constructs it; the loop below is `predict_image_caption_sequence` with the decoder swapped.
+# The restatement follows the code AS WRITTEN:
+#   * `MultiHeadAttention(hidden_size, num_heads)` binds positionally to
+#     (num_heads=hidden_size, key_dim=num_heads) (`transform_decoder.py:65-72` against
+#     `attention.py:259-262`); `heads` and `key_dim` are free parameters here, the as-written
+#     model has heads = hidden_size, key_dim = params["num_heads"].
+#   * the additive causal bias (0 valid, -1e9 masked, `attention.py:160-180`) is handed over as
+#     `attention_mask` and goes through `(1 - mask) * -1e9` (`attention.py:471-473`): valid
+#     positions get -1e9 added, masked ones about -1e18 (`mask_mode="as_written"`; "causal" is
+#     the conventional additive bias).
+#   * the pre-norm wrapper normalises only its first argument (`transform_decoder.py:35-38`):
+#     the self-attention query comes from LayerNorm(x), key and value from the raw x
+#     (`kv_from_normed=False` as written).
+#   * no cache: every step re-runs the whole prefix [0, start, ...] (`:177`, `:233-235`).
+# TF 2.3 contracts used: EinsumDense "abc,cde->abde" (+ bias [d,e]) and "abcd,cde->abe";
+# LayerNormalization(axis=-1, epsilon=1e-6) = (x-mean)/sqrt(var+eps)*gamma+beta with the
+# biased variance; Embedding = row gather; Softmax over the last axis.
+# ----------------------------------------------------------------------------------
+
+def relative_position_embedding(length, hidden_size, min_timescale=1.0, max_timescale=1.0e4):
+    """`RelativePositionEmbedding.call` (`embedding/position_embedding.py:67-102`), float32:
+    [length, hidden] = [sin(pos * inv_timescales) | cos(pos * inv_timescales)]."""
+    position = np.arange(length, dtype=np.float32)
+    num_timescales = hidden_size // 2
+    inc = np.float32(math.log(float(max_timescale) / float(min_timescale))) / \
+        (np.float32(num_timescales) - np.float32(1))
+    inv = np.float32(min_timescale) * np.exp(np.arange(num_timescales, dtype=np.float32) * -inc)
+    scaled = position[:, None] * inv[None, :].astype(np.float32)
+    return np.concatenate([np.sin(scaled), np.cos(scaled)], axis=1).astype(np.float32)
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    mean = np.mean(x, axis=-1, keepdims=True, dtype=x.dtype)
+    var = np.mean(np.square(x - mean), axis=-1, keepdims=True, dtype=x.dtype)
+    return (x - mean) / np.sqrt(var + x.dtype.type(eps)) * gamma + beta
+
+
+def decoder_self_attention_bias(length, dtype=np.float32):
+    """`get_decoder_self_attention_bias` (`attention/attention.py:160-180`): [1,1,T,T], 0 on and
+    below the diagonal, -1e9 above."""
+    valid = np.tril(np.ones((length, length), dtype=dtype))
+    return (dtype(-1e9) * (dtype(1.0) - valid)).reshape(1, 1, length, length)
+
+
+def multi_head_attention(query, value, p, prefix, heads, key_dim, attention_mask=None):
+    """`MultiHeadAttention.call` (`attention/attention.py:526-562`) with key = value.
+    query [B,T,Dq], value [B,S,Dv]; kernels `prefix + q/k/v_kernel` [Din, heads*key_dim],
+    `o_kernel` [heads*key_dim, Dq].  `attention_mask` (broadcastable to [B,heads,T,S]) goes
+    through `(1 - mask) * -1e9` exactly as `_masked_softmax` does (`:461-474`)."""
+    B, T, _ = query.shape
+    S = value.shape[1]
+    dt = query.dtype
+    q = (dense(query, p[prefix + "q_kernel"], p[prefix + "q_bias"])).reshape(B, T, heads, key_dim)
+    k = (dense(value, p[prefix + "k_kernel"], p[prefix + "k_bias"])).reshape(B, S, heads, key_dim)
+    v = (dense(value, p[prefix + "v_kernel"], p[prefix + "v_bias"])).reshape(B, S, heads, key_dim)
+    q = q * dt.type(1.0 / math.sqrt(float(key_dim)))
+    scores = np.einsum("aecd,abcd->acbe", k, q)                      # [B,heads,T,S]
+    if attention_mask is not None:
+        with np.errstate(over="ignore"):
+            adder = (dt.type(1.0) - attention_mask.astype(dt)) * dt.type(-1e9)
+        scores = scores + adder
+    w = softmax(scores, axis=-1)
+    out = np.einsum("acbe,aecd->abcd", w, v).reshape(B, T, heads * key_dim)
+    return dense(out, p[prefix + "o_kernel"], p[prefix + "o_bias"])
+
+
+def transformer_decoder_stack(p, x, encoder_outputs, n_layers, heads, key_dim,
+                              mask_mode="as_written", kv_from_normed=False):
+    """`DecoderStack.call` (`decoder/transform_decoder.py:92-151`) with the pre-norm wrapper
+    (`:30-42`): x += sublayer(LayerNorm(x), ...) for self-attention, encoder-decoder attention
+    and the feed-forward network, then the output LayerNorm."""
+    T = x.shape[1]
+    bias = decoder_self_attention_bias(T, x.dtype.type)
+    if mask_mode == "as_written":
+        self_mask = bias                      # the bias travels as `attention_mask`
+    elif mask_mode == "causal":
+        self_mask = np.tril(np.ones((T, T), x.dtype)).reshape(1, 1, T, T)
+    else:
+        raise ValueError("mask_mode must be 'as_written' or 'causal'")
+    for l in range(n_layers):
+        pre = "l%d_" % l
+        y = layer_norm(x, p[pre + "self_ln_gamma"], p[pre + "self_ln_beta"])
+        x = x + multi_head_attention(y, y if kv_from_normed else x, p, pre + "self_", heads,
+                                     key_dim, attention_mask=self_mask)
+        y = layer_norm(x, p[pre + "cross_ln_gamma"], p[pre + "cross_ln_beta"])
+        x = x + multi_head_attention(y, encoder_outputs, p, pre + "cross_", heads, key_dim)
+        y = layer_norm(x, p[pre + "ffn_ln_gamma"], p[pre + "ffn_ln_beta"])
+        f = np.maximum(dense(y, p[pre + "ffn_filter_kernel"], p[pre + "ffn_filter_bias"]), 0)
+        x = x + dense(f, p[pre + "ffn_output_kernel"], p[pre + "ffn_output_bias"])
+    return layer_norm(x, p["out_ln_gamma"], p["out_ln_beta"])
+
+
+def transform_decoder_step(p, dec_input, features, hidden, n_layers, heads, key_dim,
+                           mask_mode="as_written", kv_from_normed=False):
+    """`TransformDecoder.call` / `decode` (`decoder/transform_decoder.py:167-231`): the state
+    is the int prefix [N,len]; targets = [prefix | dec_input]; embedding + position encoding
+    (`:206-210`), the stack, fc2 on every position, the last position's logits.
+    Returns (logits[N,V], [targets], None, outputs[:, -1, :])."""
+    targets = np.concatenate([hidden[0], np.asarray(dec_input).reshape(-1, 1)], axis=-1)
+    x = p["t_embedding"][targets]                                    # Embedding: [N,len,hidden]
+    x = x + relative_position_embedding(targets.shape[1], x.shape[-1])[None].astype(x.dtype)
+    out = transformer_decoder_stack(p, x, features, n_layers, heads, key_dim, mask_mode,
+                                    kv_from_normed)
+    logits = dense(out, p["t_fc2_kernel"], p["t_fc2_bias"])
+    return logits[:, -1, :], [targets], None, out[:, -1, :]
+
+
+def predict_transformer_caption_sequence(p, img, beam_width, max_len, start_id, eos_id, n_layers,
+                                         heads, key_dim, length_penalty_weight=1.0,
+                                         tile_mode="reference", mask_mode="as_written",
+                                         kv_from_normed=False, return_trace=False):
+    """The loop of `predict_image_caption_sequence` (`recurrent_example.py:477-562`) over the
+    transformer decoder: encoder -> tile -> reset_state = zeros [N,1] int
+    (`transform_decoder.py:233-235`) -> T x (decoder step, beam step) -> back-track.  As in
+    that loop the state (here the token prefix of each row) is not reordered by parent beam."""
+    B, W = img.shape[0], beam_width
+    features = tile_features(mlp_encoder(img, p["enc_kernel"], p["enc_bias"]), W, tile_mode)
+    dec_input = np.full([B * W, 1], start_id, np.int32)
+    hidden = [np.zeros((B * W, 1), np.int32)]
+    V = p["t_fc2_kernel"].shape[1]
+    state = create_initial_beam_state_batch(B, W, dtype=img.dtype)
+    config = BeamSearchConfig(W, V, eos_id, length_penalty_weight, choose_top_k)
+    seq, trace = [], []
+    for i in range(max_len):
+        logits, hidden, _, last = transform_decoder_step(p, dec_input, features, hidden, n_layers,
+                                                         heads, key_dim, mask_mode, kv_from_normed)
+        logits3 = logits.reshape(-1, W, V)
+        out, state = beam_search_step_batch(i, logits3, state, config)
+        seq.append((out, state))
+        if return_trace:
+            trace.append({"logits": logits3, "out": out, "state": state, "last": last})
+        dec_input = out.predicted_ids.reshape(-1, 1)
+    tokens = np.concatenate(loc_optimal_beam_path_batch(seq), axis=1).astype(np.int32)
+    return (tokens, trace) if return_trace else tokens
+
+
+def make_transformer_params(seed, F, D, V, hidden, n_layers, heads, key_dim, filter_size):
+    """Synthetic weights of the transformer path: Glorot-uniform kernels (EinsumDense fans
+    taken over the flattened [in, heads*key_dim] matrices), zero biases, LayerNorm gamma 1 /
+    beta 0, embedding U(-0.05, 0.05); the MLP encoder as in `make_params` (features dim D)."""
+    rng = np.random.default_rng([seed, 104729])
+    HD = heads * key_dim
+    p = {"enc_kernel": _glorot(rng, F, D), "enc_bias": np.zeros(D, np.float32),
+         "t_embedding": rng.uniform(-0.05, 0.05, size=(V, hidden)).astype(np.float32),
+         "t_fc2_kernel": _glorot(rng, hidden, V), "t_fc2_bias": np.zeros(V, np.float32),
+         "out_ln_gamma": np.ones(hidden, np.float32), "out_ln_beta": np.zeros(hidden, np.float32)}
+    for l in range(n_layers):
+        pre = "l%d_" % l
+        for att, d_kv in (("self_", hidden), ("cross_", D)):
+            p[pre + att + "q_kernel"] = _glorot(rng, hidden, HD)
+            p[pre + att + "k_kernel"] = _glorot(rng, d_kv, HD)
+            p[pre + att + "v_kernel"] = _glorot(rng, d_kv, HD)
+            p[pre + att + "o_kernel"] = _glorot(rng, HD, hidden)
+            for b in ("q_bias", "k_bias", "v_bias"):
+                p[pre + att + b] = np.zeros(HD, np.float32)
+            p[pre + att + "o_bias"] = np.zeros(hidden, np.float32)
+        for ln in ("self_ln_", "cross_ln_", "ffn_ln_"):
+            p[pre + ln + "gamma"] = np.ones(hidden, np.float32)
+            p[pre + ln + "beta"] = np.zeros(hidden, np.float32)
+        p[pre + "ffn_filter_kernel"] = _glorot(rng, hidden, filter_size)
+        p[pre + "ffn_filter_bias"] = np.zeros(filter_size, np.float32)
+        p[pre + "ffn_output_kernel"] = _glorot(rng, filter_size, hidden)
+        p[pre + "ffn_output_bias"] = np.zeros(hidden, np.float32)
+    return p
+
+
+def perturb_transformer_params(p, seed, scale=0.05):
+    """Non-trivial biases and LayerNorm gamma / beta so that tests exercise them."""
+    rng = np.random.default_rng(seed)
+    q = dict(p)
+    for k, v in p.items():
+        if k.endswith("_bias") or k.endswith("_beta") or k.endswith("_gamma"):
+            q[k] = (v + rng.normal(0, scale, size=v.shape)).astype(np.float32)
+    return q

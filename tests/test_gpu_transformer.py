@@ -1,0 +1,184 @@
+"""Transformer decoder path (reference decoder/transform_decoder.py, attention/attention.py,
+decoder/ffn_layer.py, embedding/position_embedding.py) vs the oracle.
+
+No reference test, fixture or driver covers this decoder: parity unpinned; the checker is the
+oracle's full-prefix restatement of the code as written (heads = hidden_size x key_dim =
+num_heads, bias-as-mask, keys / values from the un-normalised input), which also validates the
+engine's incremental form (per-row key / value caches).  Bars as for the recurrent path: 1e-5
+relative on activations and log-probs (a few 1e-5 after many layers), identical tokens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caption_oracle as co
+from tests.helpers import assert_close, dev, np_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from image_caption_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("length,hidden", [(5, 8), (22, 512), (3, 36)])
+def test_position_table(ops, length, hidden):
+    got = np_of(ops.position_table(length, hidden, dev()))
+    ref = co.relative_position_embedding(length, hidden)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_embed_pos(ops):
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((11, 12)).astype(np.float32)
+    ids = rng.integers(0, 11, size=7).astype(np.int32)
+    row = rng.standard_normal(12).astype(np.float32)
+    got = np_of(ops.embed_pos(to_dev(table), to_dev(ids), to_dev(row)))
+    np.testing.assert_array_equal(got, table[ids] + row[None])
+
+
+@pytest.mark.parametrize("N,D,with_o", [(5, 8, False), (7, 36, True), (130, 512, True), (3, 2048, True)])
+def test_residual_layernorm(ops, N, D, with_o):
+    rng = np.random.default_rng(N + D)
+    x = rng.standard_normal((N, D)).astype(np.float32) * 2 + 0.5
+    o = rng.standard_normal((N, D)).astype(np.float32) if with_o else None
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    xd = to_dev(x.copy())
+    y = ops.residual_layernorm(xd, to_dev(o) if with_o else None, to_dev(g), to_dev(b))
+    xs = (x + o) if with_o else x
+    np.testing.assert_array_equal(np_of(xd), xs)
+    ref = co.layer_norm(xs.astype(np.float64), g.astype(np.float64), b.astype(np.float64))
+    assert_close(np_of(y), ref, what="layernorm")
+
+
+@pytest.mark.parametrize("N,heads,kd,pos,mask_mode", [
+    (3, 4, 4, 0, 0), (3, 4, 4, 3, 1), (5, 6, 8, 4, 0), (5, 6, 8, 4, 1), (4, 2, 64, 5, 1),
+    (6, 512, 8, 7, 0), (6, 8, 64, 7, 1), (2, 3, 16, 2, 1)])
+def test_mha_self_step(ops, N, heads, kd, pos, mask_mode):
+    rng = np.random.default_rng(N * heads + kd + pos)
+    HD = heads * kd
+    Tcap = pos + 2
+    q = rng.standard_normal((N, HD)).astype(np.float32)
+    kv = rng.standard_normal((Tcap, N, 2 * HD)).astype(np.float32)
+    got = np_of(ops.mha_self_step(to_dev(q), to_dev(kv), heads, kd, pos, mask_mode))
+    qs = (q * np.float32(1.0 / np.sqrt(kd))).reshape(N, heads, kd)
+    k = kv[:pos + 1, :, :HD].reshape(pos + 1, N, heads, kd)
+    v = kv[:pos + 1, :, HD:].reshape(pos + 1, N, heads, kd)
+    s = np.einsum("jnhd,nhd->nhj", k, qs).astype(np.float32)
+    if mask_mode == 0:
+        s = s + np.float32(-1e9)            # every visible position, in fp32 (attention.py:471-473)
+    w = co.softmax(s.astype(np.float64), axis=-1)
+    ref = np.einsum("nhj,jnhd->nhd", w, v).reshape(N, HD)
+    assert_close(got, ref, what="self attention")
+    if mask_mode == 0:
+        # the absorbed scores make the weights uniform: a causal mean of the values
+        np.testing.assert_allclose(got, v.mean(axis=0).reshape(N, HD), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("G,R,L,heads,kd,mode", [
+    (3, 1, 5, 4, 4, 0), (3, 3, 5, 4, 8, 0), (3, 3, 5, 4, 8, 1), (2, 5, 7, 2, 64, 0),
+    (4, 3, 64, 512, 8, 0), (4, 4, 9, 3, 16, 1)])
+def test_mha_cross_step(ops, G, R, L, heads, kd, mode):
+    rng = np.random.default_rng(G * R + L + kd)
+    HD, N = heads * kd, G * R
+    q = rng.standard_normal((N, HD)).astype(np.float32)
+    kv = rng.standard_normal((G, L, 2 * HD)).astype(np.float32)
+    sg, sk = (R, 1) if mode == 1 else (1, G)
+    got = np_of(ops.mha_cross_step(to_dev(q), to_dev(kv), G, R, sg, sk, heads, kd))
+    ref = np.zeros((N, HD))
+    for g in range(G):
+        k = kv[g, :, :HD].reshape(L, heads, kd).astype(np.float64)
+        v = kv[g, :, HD:].reshape(L, heads, kd).astype(np.float64)
+        for r in range(R):
+            n = g * sg + r * sk
+            qs = (q[n].astype(np.float64) / np.sqrt(kd)).reshape(heads, kd)
+            w = co.softmax(np.einsum("lhd,hd->hl", k, qs), axis=-1)
+            ref[n] = np.einsum("hl,lhd->hd", w, v).reshape(HD)
+    assert_close(got, ref, what="cross attention")
+
+
+def _compare(dims, seed, B, L, T, W, tile_mode, mask_mode="as_written", kv_from_normed=False,
+             rtol=2e-5, perturb=True):
+    from image_caption_amd.tengine import TransformerConfig, TransformerEngine
+    p = co.make_transformer_params(seed, **dims)
+    if perturb:
+        p = co.perturb_transformer_params(p, seed + 1)
+    img = co.make_images(seed + 50, B, L, dims["F"])
+    tok_o, trace_o = co.predict_transformer_caption_sequence(
+        p, img, W, T, 3, 4, dims["n_layers"], dims["heads"], dims["key_dim"], 1.0, tile_mode,
+        mask_mode, kv_from_normed, return_trace=True)
+    cfg = TransformerConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], hidden=dims["hidden"],
+                            heads=dims["heads"], key_dim=dims["key_dim"], filter=dims["filter_size"],
+                            layers=dims["n_layers"], V=dims["V"], T=T, tile_mode=tile_mode,
+                            mask_mode=mask_mode, kv_from_normed=kv_from_normed)
+    eng = TransformerEngine(cfg, p, device=dev())
+    tok_g, _ = eng.decode(to_dev(img))
+    tr = eng.trace()
+    last = np_of(eng.last_output())
+    eng.close()
+    tok_g = np_of(tok_g)
+    ids_o = np.stack([st["out"].predicted_ids for st in trace_o])
+    par_o = np.stack([st["out"].beam_parent_ids for st in trace_o])
+    lp_o = np.stack([st["state"].log_probs for st in trace_o])
+    same = (np_of(tr["ids"]) == ids_o).all(axis=(0, 2)) & (np_of(tr["parents"]) == par_o).all(axis=(0, 2))
+    nbad = int((~same).sum())
+    with np.errstate(over="ignore"):
+        assert_close(np.maximum(np_of(tr["log_probs"])[:, same], -1e30), np.maximum(lp_o[:, same], -1e30),
+                     rtol=rtol, what="log_probs")
+    if nbad == 0:
+        np.testing.assert_array_equal(tok_g, tok_o)
+        assert_close(last, trace_o[-1]["last"], rtol=10 * rtol, what="last output")
+    return nbad
+
+
+SMALL = dict(F=24, D=16, V=40, hidden=32, n_layers=2, heads=32, key_dim=4, filter_size=64)
+
+
+@pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
+@pytest.mark.parametrize("W", [1, 3])
+def test_tdecode_small_as_written(tile_mode, W):
+    assert _compare(SMALL, seed=1, B=4, L=5, T=6, W=W, tile_mode=tile_mode) == 0
+
+
+def test_tdecode_small_conventional_variant():
+    dims = dict(SMALL, heads=4, key_dim=8)
+    assert _compare(dims, seed=2, B=3, L=6, T=7, W=3, tile_mode="repeat", mask_mode="causal",
+                    kv_from_normed=True) == 0
+    assert _compare(dims, seed=3, B=3, L=6, T=5, W=2, tile_mode="reference", mask_mode="causal",
+                    kv_from_normed=False) == 0
+
+
+def test_tdecode_wide_beam_unfused_vocab_path():
+    dims = dict(SMALL, V=41)                      # V % 4 != 0: logits buffer + beam kernels
+    assert _compare(dims, seed=4, B=3, L=4, T=5, W=6, tile_mode="repeat") == 0
+
+
+def test_tdecode_medium_as_written():
+    """hidden 128 (heads 128 x key_dim 8, as written), 3 layers, V 2000."""
+    dims = dict(F=64, D=128, V=2000, hidden=128, n_layers=3, heads=128, key_dim=8, filter_size=256)
+    assert _compare(dims, seed=5, B=6, L=16, T=8, W=3, tile_mode="reference", rtol=3e-5) <= 1
+
+
+def test_tdecode_config4_dims_short():
+    """The named configuration's layer shapes (6 layers, d = 512, 512 heads x 8, filter 2048,
+    V = 10000) on a few images and steps."""
+    dims = dict(F=64, D=512, V=10000, hidden=512, n_layers=6, heads=512, key_dim=8, filter_size=2048)
+    assert _compare(dims, seed=6, B=4, L=16, T=4, W=3, tile_mode="reference", rtol=5e-5,
+                    perturb=False) <= 1
+
+
+def test_tengine_rejects_bad_config():
+    from image_caption_amd._lib import IcapError
+    from image_caption_amd.tengine import TransformerConfig, TransformerEngine
+    p = co.make_transformer_params(0, **SMALL)
+    cfg = TransformerConfig(B=2, W=2, L=4, F=24, D=16, hidden=32, heads=16, key_dim=6, filter=64,
+                            layers=2, V=40, T=3)
+    with pytest.raises((IcapError, ValueError)):
+        TransformerEngine(cfg, p, device=dev())
+    with pytest.raises(KeyError):
+        q = dict(p)
+        del q["l1_ffn_output_bias"]
+        TransformerEngine(TransformerConfig(B=2, W=2, L=4, F=24, D=16, hidden=32, heads=32, key_dim=4,
+                                            filter=64, layers=2, V=40, T=3), q, device=dev())
