@@ -40,6 +40,12 @@ CONFIGS = {
     # at the headline shape: encoded features in, start-token mask, time from 1, 20 steps
     "searcher_b512_fp32": dict(B=512, W=3, L=64, F=256, D=256, E=256, H=512, U=512, V=10000, T=20,
                                precision="fp32", loop="searcher"),
+    # BASELINE.json configs[3]: transformer decoder, 6 layers, d = 512, beam 3, batch 1024
+    # (as the reference is written: 512 heads x key_dim 8, filter 2048 - the reference has no
+    # params dict for it, 2048 and 8 are the "Attention is all you need" base values)
+    "transformer_b1024_fp32": dict(B=1024, W=3, L=64, F=2048, D=512, hidden=512, heads=512, key_dim=8,
+                                   filter=2048, layers=6, V=10000, T=20, precision="fp32",
+                                   loop="transformer"),
     "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
                              precision="fp32"),
 }
@@ -128,6 +134,110 @@ def cpu_baseline_searcher(cfg, budget_s):
                       % (reps, Bs, cfg["W"], cfg["T"], cfg["V"], el)}
 
 
+def transformer_main(args, cfg, device, world, rank):
+    """bench line of the transformer decoder path (same contract; dominant kernels: the
+    q / k|v / output projections of the layer stack on the exact-f32 MFMA kernels)."""
+    import torch.distributed as dist
+    from image_caption_amd import synthetic
+    from image_caption_amd.distributed import all_gather_sequences
+    from image_caption_amd.tengine import TransformerConfig, TransformerEngine
+    p = synthetic.make_transformer_params(0, cfg["F"], cfg["D"], cfg["V"], cfg["hidden"], cfg["layers"],
+                                          cfg["heads"], cfg["key_dim"], cfg["filter"])
+    eng = TransformerEngine(TransformerConfig(tile_mode=args.tile_mode, **cfg), p, device=device)
+    img = torch.from_numpy(synthetic.make_images(100 + rank, cfg["B"], cfg["L"], cfg["F"])).to(device)
+    tokens = torch.empty(cfg["B"], cfg["T"], dtype=torch.int32, device=device)
+    scores = torch.empty(cfg["B"], dtype=torch.float32, device=device)
+
+    def step():
+        eng.decode(img, out=tokens, scores=scores)
+        return all_gather_sequences(tokens) if world > 1 else tokens
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.set_timing(["proj"])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    proj_ms, proj_n = eng.kernel_times()["proj"]
+    eng.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[0] == cfg["B"] * world
+    eng.set_timing(True)
+    diag = min(args.steps, 2)
+    for _ in range(diag):
+        step()
+    sync()
+    ktimes = eng.kernel_times()
+    eng.set_timing(False)
+    if rank == 0:
+        N, H, HD = cfg["B"] * cfg["W"], cfg["hidden"], cfg["heads"] * cfg["key_dim"]
+        passes = cfg["T"] + 1
+        # per pass and layer: q (H x HD), k|v (H x 2HD), o (HD x H), cross q (H x HD), cross o
+        proj_flops = 2.0 * N * H * HD * 6 * cfg["layers"] * passes * args.steps
+        achieved = proj_flops / (proj_ms * 1e-3) / 1e12 if proj_ms else 0.0
+        line = {
+            "metric": "captions/sec (beam=%d, len %d)" % (cfg["W"], cfg["T"]),
+            "value": round(cfg["B"] * world * args.steps / elapsed, 1), "unit": "captions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "images_per_gpu": cfg["B"], "beam_width": cfg["W"],
+                       "decode_steps": cfg["T"], "layers": cfg["layers"], "hidden": H,
+                       "heads": cfg["heads"], "key_dim": cfg["key_dim"], "filter": cfg["filter"],
+                       "vocab": cfg["V"], "tile_mode": args.tile_mode,
+                       "sharding": "images split over ranks, all-gather of sequences"},
+            "roofline": {"bound": "mfma", "kernel": "attention projections dense_f32 (q, k|v, output; "
+                         "5 launches per layer and pass)", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_us": round(proj_ms / max(proj_n, 1) * 1e3, 2), "launches": proj_n},
+            "kernel_ms_per_step": {k: round(v[0] / diag, 4) for k, v in ktimes.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_transformer(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_transformer(cfg, budget_s=12.0):
+    """The oracle (full-prefix recompute every step, as the reference's decoder does) on a
+    bounded sample: B=4 images, same layer shapes, beam width and steps."""
+    from oracle import caption_oracle as co
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    Bs = 4
+    p = co.make_transformer_params(0, cfg["F"], cfg["D"], cfg["V"], cfg["hidden"], cfg["layers"],
+                                   cfg["heads"], cfg["key_dim"], cfg["filter"])
+    img = co.make_images(1, Bs, cfg["L"], cfg["F"])
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        co.predict_transformer_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, cfg["layers"],
+                                                cfg["heads"], cfg["key_dim"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 20:
+            break
+    return {"value": round(Bs * reps / el, 3), "unit": "captions/s", "cores": threads, "kind": "port",
+            "sample": "%d decodes of B=%d images (beam %d, %d steps, %d layers, V=%d), numpy oracle, "
+                      "%.1f s" % (reps, Bs, cfg["W"], cfg["T"], cfg["layers"], cfg["V"], el)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +267,8 @@ def main():
     cfg = dict(CONFIGS[args.config])
     precision = cfg.pop("precision")
     loop = cfg.pop("loop", "decode")
+    if loop == "transformer":
+        return transformer_main(args, cfg, device, world, rank)
     p = synthetic.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"], cfg["U"])
     if cfg.get("cell") == "gru":
         p = synthetic.add_gru_params(p, 0)

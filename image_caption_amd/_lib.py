@@ -121,9 +121,10 @@ SIGNATURES = {
     "icap_decode": ([_P, _P, _P, _P, _P], C.c_int),
     "icap_position_table_f32": ([_P, _I, _I, _P], C.c_int),
     "icap_embed_pos_f32": ([_P, _P, _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_add_f32": ([_P, _P, C.c_longlong, C.c_longlong, _P], C.c_int),
     "icap_residual_layernorm_f32": ([_P, _P, _P, _P, _P, _I, _I, _F, _P], C.c_int),
     "icap_mha_self_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
-    "icap_mha_cross_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_mha_cross_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "icap_tengine_create": ([_P, _P, _P], C.c_int),
     "icap_tengine_destroy": ([_P], C.c_int),
     "icap_tengine_refresh_weights": ([_P, _P], C.c_int),

@@ -35,8 +35,9 @@ int embed_pos_f32(const float*, const int32_t*, const float*, float*, int, int, 
 int residual_layernorm_f32(float*, const float*, const float*, const float*, float*, int, int, float,
                            hipStream_t);
 int mha_self_step_f32(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+int add_f32(float*, const float*, long long, long long, hipStream_t);
 int mha_cross_step_f32(const float*, const float*, float*, int, int, int, int, int, int, int,
-                       hipStream_t);
+                       const float*, int, hipStream_t);
 
 namespace {
 
@@ -214,7 +215,7 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     {
       TTimed t(e, ICAP_TK_CROSS_ATT, s);
       ICAP_TTRY(mha_cross_step_f32(e->q, e->kv_cross[l], e->att, c.B, c.W, stride_g, stride_k, c.L,
-                                   c.heads, c.key_dim, s));
+                                   c.heads, c.key_dim, nullptr, 0, s));
     }
     {
       TTimed t(e, ICAP_TK_PROJ, s);
@@ -306,6 +307,10 @@ int icap_embed_pos_f32(const float* table, const int32_t* ids, const float* pos_
   return embed_pos_f32(table, ids, pos_row, x, N, V, D, (hipStream_t)stream);
 }
 
+int icap_add_f32(float* x, const float* o, long long n, long long period, icap_stream_t stream) {
+  return add_f32(x, o, n, period, (hipStream_t)stream);
+}
+
 int icap_residual_layernorm_f32(float* x, const float* o, const float* gamma, const float* beta,
                                 float* y, int N, int D, float eps, icap_stream_t stream) {
   return residual_layernorm_f32(x, o, gamma, beta, y, N, D, eps, (hipStream_t)stream);
@@ -318,9 +323,9 @@ int icap_mha_self_step_f32(const float* q, const float* kv_cache, float* out, in
 
 int icap_mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int rows_per_group,
                             int row_stride_g, int row_stride_k, int L, int heads, int key_dim,
-                            icap_stream_t stream) {
+                            const float* mask, int mask_per_group, icap_stream_t stream) {
   return mha_cross_step_f32(q, kv, out, G, rows_per_group, row_stride_g, row_stride_k, L, heads,
-                            key_dim, (hipStream_t)stream);
+                            key_dim, mask, mask_per_group, (hipStream_t)stream);
 }
 
 int icap_tengine_refresh_weights(icap_tengine* e, icap_stream_t stream) {

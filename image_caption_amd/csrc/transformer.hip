@@ -191,6 +191,8 @@ struct CrossArgs {
   int G, R, stride_g, stride_k;  // row of (image g, beam k) = g*stride_g + k*stride_k
   int L, HD, lph;
   float scale;
+  const float* mask;  // optional [G or 1][R][L] attention_mask, applied as (1 - mask) * -1e9
+  int mask_stride_g;  // R*L, or 0 when one mask serves every group
 };
 
 // Workgroup = (image, 256 chunks): the K / V slices of the image are read once and applied to
@@ -215,11 +217,17 @@ __global__ __launch_bounds__(NT) void mha_cross_step_kernel(CrossArgs p) {
       for (int e = 0; e < CH; ++e) q[r][e] = qc.e[e] * p.scale;
       st[r].init();
     }
+    const float* mrow = p.mask ? p.mask + (size_t)g * p.mask_stride_g : nullptr;
     for (int j = 0; j < p.L; ++j) {
       const Chunk<CH> kc = load_chunk<CH>(kbase + (size_t)j * 2 * p.HD);
       const Chunk<CH> vc = load_chunk<CH>(kbase + (size_t)j * 2 * p.HD + p.HD);
 #pragma unroll
-      for (int r = 0; r < RB; ++r) st[r].add(head_dot<CH>(q[r], kc, p.lph), vc);
+      for (int r = 0; r < RB; ++r) {
+        float sc = head_dot<CH>(q[r], kc, p.lph);
+        // MultiHeadAttention._masked_softmax, attention.py:471-473, in fp32
+        if (mrow) sc = sc + (1.0f - mrow[(size_t)min(k0 + r, p.R - 1) * p.L + j]) * -1e9f;
+        st[r].add(sc, vc);
+      }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -230,6 +238,14 @@ __global__ __launch_bounds__(NT) void mha_cross_step_kernel(CrossArgs p) {
       }
     }
   }
+}
+
+// x[i] += o[i % period]: the residual add of the pre-norm wrapper (period = n) and the
+// position-encoding add broadcast over the batch (period = length * hidden).
+__global__ __launch_bounds__(NT) void add_kernel(float* __restrict__ x, const float* __restrict__ o,
+                                                 long long n, long long period) {
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i < n) x[i] += o[i % period];
 }
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -245,6 +261,15 @@ int embed_pos_f32(const float* table, const int32_t* ids, const float* pos_row, 
   hipLaunchKernelGGL(embed_pos_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, table,
                      ids, pos_row, x, N, V, D / 4);
   ICAP_LAUNCH_CHECK("embed_pos_kernel");
+  return ICAP_OK;
+}
+
+int add_f32(float* x, const float* o, long long n, long long period, hipStream_t s) {
+  ICAP_REQUIRE(x && o, "add_f32: null pointer");
+  ICAP_REQUIRE(n > 0 && period > 0 && period <= n, "add_f32: bad sizes");
+  ICAP_REQUIRE(n / NT < (1LL << 31), "add_f32: too many elements");
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, s, x, o, n, period);
+  ICAP_LAUNCH_CHECK("add_kernel");
   return ICAP_OK;
 }
 
@@ -287,7 +312,7 @@ int mha_self_step_f32(const float* q, const float* kv_cache, float* out, int N, 
 
 int mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int rows_per_group,
                        int row_stride_g, int row_stride_k, int L, int heads, int key_dim,
-                       hipStream_t s) {
+                       const float* mask, int mask_per_group, hipStream_t s) {
   ICAP_REQUIRE(q && kv && out, "mha_cross_step_f32: null pointer");
   ICAP_REQUIRE(G > 0 && rows_per_group > 0 && L > 0 && heads > 0 && key_dim > 0,
                "mha_cross_step_f32: bad shape");
@@ -298,7 +323,7 @@ int mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int r
   ICAP_REQUIRE(pow2(lph) && lph <= 64,
                "mha_cross_step_f32: key_dim / %d must be a power of two up to 64 (key_dim %d)", ch, key_dim);
   CrossArgs a{q, kv, out, G, rows_per_group, row_stride_g, row_stride_k, L, heads * key_dim, lph,
-              1.0f / sqrtf((float)key_dim)};
+              1.0f / sqrtf((float)key_dim), mask, mask_per_group ? rows_per_group * L : 0};
   const int cblocks = ceil_div(a.HD / ch, NT);
   ICAP_REQUIRE((long long)G * cblocks < (1LL << 31), "mha_cross_step_f32: too many workgroups");
   const dim3 grid((unsigned)(G * cblocks)), block(NT);

@@ -197,6 +197,15 @@ def embed_pos(table, ids, pos_row):
     return x
 
 
+def add_(x, o):
+    """x += o in place; o either has x's size or is broadcast over the leading axes."""
+    n, period = x.numel(), o.numel()
+    if n % period:
+        raise ValueError("add_: the addend does not tile the tensor")
+    _lib.call("icap_add_f32", _chk(x, f32, "x"), _chk(o, f32, "o"), n, period, current_stream())
+    return x
+
+
 def residual_layernorm(x, o, gamma, beta, eps=1e-6):
     """x += o in place (o may be None); returns LayerNorm(x) * gamma + beta."""
     D = x.shape[-1]
@@ -218,13 +227,21 @@ def mha_self_step(q, kv_cache, heads, key_dim, pos, mask_mode=0):
     return out
 
 
-def mha_cross_step(q, kv, G, rows_per_group, row_stride_g, row_stride_k, heads, key_dim):
-    """q [N, heads*key_dim], kv [G, L, 2*heads*key_dim] -> combined values [N, heads*key_dim]."""
+def mha_cross_step(q, kv, G, rows_per_group, row_stride_g, row_stride_k, heads, key_dim, mask=None):
+    """q [N, heads*key_dim], kv [G, L, 2*heads*key_dim] -> combined values [N, heads*key_dim].
+    mask: attention_mask values [G, rows_per_group, L] or [rows_per_group, L] (one block for
+    every group), applied as (1 - mask) * -1e9 on the scores."""
     L = kv.shape[1]
     out = torch.empty_like(q)
+    per_group = 0
+    if mask is not None:
+        if tuple(mask.shape) == (G, rows_per_group, L):
+            per_group = 1
+        elif tuple(mask.shape) != (rows_per_group, L):
+            raise ValueError("mha_cross_step: mask must be [G,R,L] or [R,L]")
     _lib.call("icap_mha_cross_step_f32", _chk(q, f32, "q"), _chk(kv, f32, "kv"), out.data_ptr(),
               int(G), int(rows_per_group), int(row_stride_g), int(row_stride_k), int(L), int(heads),
-              int(key_dim), current_stream())
+              int(key_dim), _opt(mask, f32, "mask"), per_group, current_stream())
     return out
 
 

@@ -59,6 +59,36 @@ def add_gru_params(p, seed):
     return q
 
 
+def make_transformer_params(seed, F, D, V, hidden, layers, heads, key_dim, filter_size):
+    """Weights of the transformer decoder path under the TransformerEngine's names:
+    Glorot-uniform kernels (attention projections as flattened [in, heads*key_dim] matrices),
+    zero biases, LayerNorm gamma 1 / beta 0, embedding U(-0.05, 0.05)."""
+    rng = np.random.default_rng([seed, 104729])
+    HD = heads * key_dim
+    p = {"enc_kernel": _glorot(rng, F, D), "enc_bias": np.zeros(D, np.float32),
+         "t_embedding": rng.uniform(-0.05, 0.05, size=(V, hidden)).astype(np.float32),
+         "t_fc2_kernel": _glorot(rng, hidden, V), "t_fc2_bias": np.zeros(V, np.float32),
+         "out_ln_gamma": np.ones(hidden, np.float32), "out_ln_beta": np.zeros(hidden, np.float32)}
+    for l in range(layers):
+        pre = "l%d_" % l
+        for att, d_kv in (("self_", hidden), ("cross_", D)):
+            p[pre + att + "q_kernel"] = _glorot(rng, hidden, HD)
+            p[pre + att + "k_kernel"] = _glorot(rng, d_kv, HD)
+            p[pre + att + "v_kernel"] = _glorot(rng, d_kv, HD)
+            p[pre + att + "o_kernel"] = _glorot(rng, HD, hidden)
+            for b in ("q_bias", "k_bias", "v_bias"):
+                p[pre + att + b] = np.zeros(HD, np.float32)
+            p[pre + att + "o_bias"] = np.zeros(hidden, np.float32)
+        for ln in ("self_ln_", "cross_ln_", "ffn_ln_"):
+            p[pre + ln + "gamma"] = np.ones(hidden, np.float32)
+            p[pre + ln + "beta"] = np.zeros(hidden, np.float32)
+        p[pre + "ffn_filter_kernel"] = _glorot(rng, hidden, filter_size)
+        p[pre + "ffn_filter_bias"] = np.zeros(filter_size, np.float32)
+        p[pre + "ffn_output_kernel"] = _glorot(rng, filter_size, hidden)
+        p[pre + "ffn_output_bias"] = np.zeros(hidden, np.float32)
+    return p
+
+
 def make_images(seed, B, L, F):
     """max(0, N(0,1)) * 0.5: non-negative, about half zeros, like post-ReLU CNN maps."""
     rng = np.random.default_rng(seed)

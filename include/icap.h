@@ -422,6 +422,10 @@ int icap_position_table_f32(float* table, int length, int hidden, icap_stream_t 
  * encoding of one target position, transform_decoder.py:206-210.  D % 4 == 0. */
 int icap_embed_pos_f32(const float* table, const int32_t* ids, const float* pos_row, float* x,
                        int N, int V, int D, icap_stream_t stream);
+/* x[i] += o[i % period] in place, i < n: the wrapper's residual add x + y
+ * (transform_decoder.py:42; period = n) and the position-encoding add broadcast over the
+ * batch (transform_decoder.py:210; period = length * hidden). */
+int icap_add_f32(float* x, const float* o, long long n, long long period, icap_stream_t stream);
 /* Pre-norm wrapper arithmetic (transform_decoder.py:35,42): x += o when o != NULL (in
  * place), then y = LayerNormalization(x) * gamma + beta over the last axis with the biased
  * variance and epsilon `eps` (the stack uses 1e-6).  D % 4 == 0, D <= 4096. */
@@ -436,12 +440,17 @@ int icap_residual_layernorm_f32(float* x, const float* o, const float* gamma, co
  * key_dim % 4 == 0 and key_dim / 8 (or / 4) a power of two. */
 int icap_mha_self_step_f32(const float* q, const float* kv_cache, float* out, int N, int heads,
                            int key_dim, int pos, int mask_mode, icap_stream_t stream);
-/* Encoder-decoder attention of one query position per row: kv[G][L][2*heads*key_dim] holds
- * keys then values of the L encoder outputs of image g (no mask: the stack passes
- * attention_bias = None); rows are grouped per image as in icap_attention_f32. */
+/* Multi-head attention of rows_per_group query rows per group over the group's L key / value
+ * rows: kv[G][L][2*heads*key_dim] holds keys then values (in the engine: of the L encoder
+ * outputs of image g, rows grouped per image as in icap_attention_f32; for a whole
+ * [B,T,dim] query: G = B, rows_per_group = T, row_stride_g = T, row_stride_k = 1).
+ * mask (optional): attention_mask values [G][rows_per_group][L] (mask_per_group != 0) or
+ * one [rows_per_group][L] block for every group, applied as (1 - mask) * -1e9 on the fp32
+ * scores like MultiHeadAttention._masked_softmax (attention.py:461-474); the engine's
+ * encoder-decoder attention passes none (attention_bias = None). */
 int icap_mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int rows_per_group,
                             int row_stride_g, int row_stride_k, int L, int heads, int key_dim,
-                            icap_stream_t stream);
+                            const float* mask, int mask_per_group, icap_stream_t stream);
 
 typedef struct icap_tconfig {
   int32_t B, W, L, F, D;        /* images, beam width, locations, CNN feature dim, encoder dim */

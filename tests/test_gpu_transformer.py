@@ -182,3 +182,96 @@ def test_tengine_rejects_bad_config():
         del q["l1_ffn_output_bias"]
         TransformerEngine(TransformerConfig(B=2, W=2, L=4, F=24, D=16, hidden=32, heads=32, key_dim=4,
                                             filter=64, layers=2, V=40, T=3), q, device=dev())
+
+
+def _tmodules(p, dims):
+    from image_caption_amd.decoder import TransformDecoder
+    params = {"hidden_size": dims["hidden"], "num_heads": dims["key_dim"],
+              "num_hidden_layers": dims["n_layers"], "filter_size": dims["filter_size"],
+              "attention_dropout": 0.0, "relu_dropout": 0.0, "layer_postprocess_dropout": 0.0}
+    dec = TransformDecoder(params, dims["V"], device=dev())
+    dec.load_params(p, dev())
+    return dec
+
+
+def test_multi_head_attention_layer_with_and_without_mask(ops):
+    from image_caption_amd.attention.attention import MultiHeadAttention, get_decoder_self_attention_bias
+    rng = np.random.default_rng(3)
+    B, T, S, dim, heads, kd = 3, 4, 6, 16, 5, 8
+    q_in = rng.standard_normal((B, T, dim)).astype(np.float32)
+    v_in = rng.standard_normal((B, S, 12)).astype(np.float32)
+    p = {}
+    for n, (i, o) in (("q", (dim, heads * kd)), ("k", (12, heads * kd)), ("v", (12, heads * kd)),
+                      ("o", (heads * kd, dim))):
+        p["x_" + n + "_kernel"] = (rng.standard_normal((i, o)) / np.sqrt(i)).astype(np.float32)
+        p["x_" + n + "_bias"] = (0.1 * rng.standard_normal(o)).astype(np.float32)
+    layer = MultiHeadAttention(heads, kd, device=dev())
+    layer.set_weights(*[(p["x_%s_kernel" % n], p["x_%s_bias" % n]) for n in "qkvo"], device=dev())
+    got = np_of(layer(to_dev(q_in), to_dev(v_in)))
+    ref = co.multi_head_attention(q_in, v_in, p, "x_", heads, kd)
+    assert_close(got, ref, what="mha")
+    mask = (rng.random((B, T, S)) > 0.3).astype(np.float32)
+    mask[:, :, 0] = 1
+    got = np_of(layer(to_dev(q_in), to_dev(v_in), attention_mask=to_dev(mask)))
+    ref = co.multi_head_attention(q_in, v_in, p, "x_", heads, kd, attention_mask=mask[:, None])
+    assert_close(got, ref, what="mha masked")
+    # the decoder's bias tensor handed over as a mask, self-attention shapes
+    bias = np_of(get_decoder_self_attention_bias(T, device=dev()))
+    np.testing.assert_array_equal(bias, co.decoder_self_attention_bias(T))
+    p2 = dict(p, x_k_kernel=p["x_q_kernel"], x_v_kernel=p["x_q_kernel"])
+    layer2 = MultiHeadAttention(heads, kd, device=dev())
+    layer2.set_weights(*[(p2["x_%s_kernel" % n], p2["x_%s_bias" % n]) for n in "qkvo"], device=dev())
+    got = np_of(layer2(to_dev(q_in), to_dev(q_in), attention_mask=to_dev(bias)))
+    ref = co.multi_head_attention(q_in, q_in, p2, "x_", heads, kd, attention_mask=bias)
+    assert_close(got, ref, what="mha bias-as-mask")
+
+
+def test_transform_decoder_module_steps_and_engine_agree():
+    """The module API (full-prefix recompute per call, as the reference) against the oracle
+    step, and the module-level decode loop against the fused engine."""
+    from image_caption_amd.beam_search import beam_search as bs
+    from image_caption_amd.tengine import TransformerConfig, TransformerEngine
+    dims = SMALL
+    p = co.perturb_transformer_params(co.make_transformer_params(7, **dims), 8)
+    dec = _tmodules(p, dims)
+    B, W, L, T = 3, 2, 5, 5
+    img = co.make_images(9, B, L, dims["F"])
+    feats = co.tile_features(co.mlp_encoder(img, p["enc_kernel"], p["enc_bias"]), W, "reference")
+    N = B * W
+    hidden_o = [np.zeros((N, 1), np.int32)]
+    hidden_g = dec.reset_state(torch.zeros(N, 1, device=dev()), None)
+    assert hidden_g[0].dtype == torch.int32 and tuple(hidden_g[0].shape) == (N, 1)
+    with pytest.raises(KeyError):
+        dec((torch.full((N, 1), 3, dtype=torch.int32, device=dev()), {"features": to_dev(feats)}, hidden_g))
+    st = bs.create_initial_beam_state_batch(B, W, device=dev())
+    cfg = bs.BeamSearchConfig(W, dims["V"], 4, 1.0, bs.choose_top_k)
+    dec_input = torch.full((N, 1), 3, dtype=torch.int32, device=dev())
+    ids_np = np.full((N, 1), 3, np.int32)
+    seq = []
+    feats_g = to_dev(feats)
+    for i in range(T):
+        lo, hidden_o, _, last_o = co.transform_decoder_step(p, ids_np, feats, hidden_o, dims["n_layers"],
+                                                            dims["heads"], dims["key_dim"])
+        lg, hidden_g, none, last_g = dec((dec_input, {"features": feats_g}, hidden_g), training=False)
+        assert none is None
+        np.testing.assert_array_equal(np_of(hidden_g[0]), hidden_o[0])
+        assert_close(np_of(last_g), last_o, rtol=5e-5, what="outputs step %d" % i)
+        assert_close(np_of(lg), lo, rtol=5e-5, what="logits step %d" % i)
+        out, st = bs.beam_search_step_batch(i, lg.reshape(-1, W, dims["V"]).contiguous(), st, cfg)
+        seq.append((out, st))
+        dec_input = out.predicted_ids.reshape(-1, 1)
+        ids_np = np_of(dec_input)
+    path = torch.cat(bs.loc_optimal_beam_path_batch(seq), dim=1).to(torch.int32)
+    cfg_e = TransformerConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], hidden=dims["hidden"],
+                              heads=dims["heads"], key_dim=dims["key_dim"], filter=dims["filter_size"],
+                              layers=dims["n_layers"], V=dims["V"], T=T)
+    eng = TransformerEngine(cfg_e, p, device=dev())
+    tok, _ = eng.decode(to_dev(img))
+    np.testing.assert_array_equal(np_of(tok), np_of(path))
+    # exported module weights drive the engine as well
+    from image_caption_amd.encoder import MlpEncoder
+    enc = MlpEncoder(dims["D"], name="mlp_feature_encoder", device=dev())
+    enc.fc.set_weights(p["enc_kernel"], p["enc_bias"], dev())
+    eng2 = TransformerEngine(cfg_e, dec.export_params(enc), device=dev())
+    tok2, _ = eng2.decode(to_dev(img))
+    np.testing.assert_array_equal(np_of(tok2), np_of(tok))
