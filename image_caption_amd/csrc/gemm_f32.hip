@@ -360,20 +360,41 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
   __syncthreads();  // (the top-k epilogue reuses the LDS)
 
   if constexpr (TOPK == 0) {
+    // The bias values are fetched and added before any store, and interior tiles store
+    // without per-row predicates: a load whose wait sits inside a predicated store block
+    // makes every block wait for ALL outstanding memory operations, the earlier stores
+    // included, which serialises the 32 stores of a wave.
+    const bool relu = p.act == ICAP_ACT_RELU;
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);  // uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + l31;
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+      const bool col_ok = col < p.N;
+      float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
+      asm volatile("" : "+v"(bv));  // the wait for the bias happens here, once
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < p.M) {
-            float v = acc[i][j][r] + bv;
-            if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
-            p.C[(size_t)row * p.ldc + col] = v;
+          float v = acc[i][j][r] + bv;
+          acc[i][j][r] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + (wm * TM + i) * 32 + 4 * half;
+        float* c0 = p.C + (size_t)row0 * p.ldc + col;
+        if (interior) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c0[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r];
+        } else if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (row0 + dr < p.M) c0[(size_t)dr * p.ldc] = acc[i][j][r];
           }
         }
       }

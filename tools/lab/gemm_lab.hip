@@ -14,9 +14,14 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
   const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
   tm = sid % tiles_m; tn = sid / tiles_m;
 }
-// VARIANT bits: 1 = skip global loads in loop, 2 = skip MFMA, 4 = skip LDS store+barrier in loop, 8 = skip epilogue stores
+// VARIANT bits: 1 = skip global loads in loop, 2 = skip MFMA, 4 = skip LDS store+barrier in loop, 8 = skip epilogue stores,
+// 16 = the library's schedule: next-step loads above the per-step barrier, staging registers pinned below the multiplies
 template <int BM, int BN, int WM, int WN, int VARIANT, int MINW>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void k(Args p) {
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+#ifdef WPE
+    __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
+#endif
+    void k(Args p) {
   constexpr int NT = WM * WN * 64, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_LD = (BM * BK / 4) / NT, B_LD = (BK * BN / 4) / NT;
   __shared__ float4 As[2][BK / 4][BM + 1];
@@ -44,10 +49,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void k(Args p) {
   const int nk = p.K / BK;
   const float* a_tile = p.A; const float* b_tile = p.B;
   LOADT(a_tile, b_tile) STORET(0) if (VARIANT & 4) { STORET(1) }
-  __syncthreads();
+  if (!(VARIANT & 16)) __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     if (!(VARIANT & 1)) { const bool more = t + 1 < nk; a_tile += more ? BK : 0; b_tile += more ? (size_t)BK * p.ldb : 0; LOADT(a_tile, b_tile) }
+    if (VARIANT & 16) __syncthreads();
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       float4 a[TM]; float b[TN][4];
@@ -74,7 +80,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void k(Args p) {
           for (int j = 0; j < TN; ++j) { acc[i][j][0] += a[i].x * b[j][0] + a[i].y * b[j][1] + a[i].z * b[j][2] + a[i].w * b[j][3]; }
       }
     }
-    if (!(VARIANT & 4)) { STORET(buf ^ 1) __syncthreads(); }
+    if (VARIANT & 16) {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
+      STORET(buf ^ 1)
+    } else if (!(VARIANT & 4)) { STORET(buf ^ 1) __syncthreads(); }
   }
   if (VARIANT & 8) {
     float sacc = 0.f;
@@ -137,6 +149,9 @@ int main(int argc, char** argv) {
   R(256,128,4,4,1) R(256,128,4,4,2) R(128,256,4,4,2) R(256,256,4,4,1) R(256,256,4,4,2)
   R(64,128,2,4,2) R(128,64,4,2,2) R(64,64,2,2,4)
   R(128,128,4,2,3) R(128,128,4,2,4)
+#define S(BM,BN,WM,WN,MW) run<BM,BN,WM,WN,16,MW>(a, 20, "sched " #BM "x" #BN " waves " #WM "x" #WN " minw " #MW);
+  S(128,128,4,2,2) S(128,128,2,4,2) S(128,128,4,4,2) S(256,128,4,4,1) S(128,256,4,4,1) S(128,256,2,4,1) S(256,256,4,4,1)
+  S(64,128,2,4,4) S(128,64,4,2,4) S(64,64,2,2,4) S(128,128,4,2,3) S(256,128,4,2,1) S(128,256,4,2,1)
   run<128,128,4,2,8,2>(a, 20, "128x128 4x2 no epilogue");
   run<128,128,4,2,13,2>(a, 20, "128x128 4x2 MFMA+LDS reads only");
   run<128,128,4,2,4,2>(a, 20, "128x128 4x2 no LDS store/barrier");
