@@ -793,6 +793,8 @@ int icap_search_baseline(icap_engine* e, const float* features, const int32_t* s
   ICAP_REQUIRE(e && features && tokens, "icap_search_baseline: null argument");
   ICAP_REQUIRE(pad_token >= 0 && pad_token < e->cfg.V,
                "icap_search_baseline: pad token outside the vocabulary");
+  ICAP_REQUIRE(!seq_len || (e->cfg.eos_id >= 0 && e->cfg.eos_id < e->cfg.V),
+               "icap_search_baseline: forced eos needs an eos token inside the vocabulary");
   if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;
   LoopVariant lv;
   lv.features = features;
