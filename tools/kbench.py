@@ -131,6 +131,31 @@ def main():
     run("beam all finished", lambda: ops.beam_step(logits, lp, fin1, ln, 3, 4, 1.0))
     run("beam logprob input", lambda: ops.beam_step(logits, lp, fin0, ln, 3, 4, 1.0,
                                                     input_is_log_prob=True), bytes_=nb)
+    # transformer decoder kernels at the config-4 shapes (1024 images x beam 3, 512 heads x 8)
+    Bt, Nt, Hd, heads, kd, pos = 1024, 3072, 512, 512, 8, 10
+    HD = heads * kd
+    if not a.only or any(k in a.only for k in ("mha", "layernorm", "gru")):
+        qt = rn(Nt, HD)
+        kv_self = torch.randn(pos + 1, Nt, 2 * HD, generator=g).to(dev)
+        run("mha_self_step pos=10", lambda: ops.mha_self_step(qt, kv_self, heads, kd, pos, 0),
+            bytes_=(pos + 1) * Nt * 2 * HD * 4.0 + 2 * Nt * HD * 4.0)
+        kv_cross = torch.randn(Bt, L, 2 * HD, generator=g).to(dev)
+        run("mha_cross_step", lambda: ops.mha_cross_step(qt, kv_cross, Bt, 3, 1, Bt, heads, kd),
+            bytes_=Bt * L * 2 * HD * 4.0 + 2 * Nt * HD * 4.0)
+        xt, ot, gam, bet = rn(Nt, Hd), rn(Nt, Hd), rn(Hd), rn(Hd)
+        run("residual_layernorm", lambda: ops.residual_layernorm(xt, ot, gam, bet),
+            bytes_=4 * Nt * Hd * 4.0)
+        # GRU step at the headline shape
+        k3 = rn(D + E, 3 * H) / np.sqrt(D + E)
+        r3 = rn(H, 3 * H) / np.sqrt(H)
+        b3 = torch.zeros(2, 3 * H, device=dev)
+        k4, r4, b4 = ops.gru_pack(k3, r3, b3)
+        table = rn(V, E) * 0.05
+        ids = torch.randint(0, V, (N,), generator=g).to(torch.int32).to(dev)
+        ep = ops.dense(table, k4[D:].contiguous(), None)
+        ctxg, hg = rn(N, D), rn(N, H) * 0.5
+        run("gru_step emb_proj", lambda: ops.gru_step(ctxg, hg, k4, r4, b4, ids=ids, emb_proj=ep),
+            flops=2.0 * N * (D + H) * 4 * H)
     return res
 
 
