@@ -44,5 +44,29 @@ int main() {
   hipMalloc(&rec, (size_t)M * dense_topk_half_tiles(N) * 8 * 4); hipMalloc(&eosx, M * 4);
   timeit("dense_topk_f32()", [&] { dense_topk_f32(A, B, bias, M, K, N, 4, 3, rec, eosx, nullptr, 0); }, fl);
   timeit("dense_f32() again", [&] { dense_f32(A, B, bias, C, M, K, N, 0, 0); }, fl);
+  {
+    // output projections of the transformer path: tall-skinny products
+    const int M2 = 3072, N2 = 512;
+    for (int K2 : {4096, 2048}) {
+      float *A2, *B2, *C2;
+      hipMalloc(&A2, (size_t)M2 * K2 * 4); hipMalloc(&B2, (size_t)K2 * N2 * 4); hipMalloc(&C2, (size_t)M2 * N2 * 4);
+      hipMemset(A2, 0, (size_t)M2 * K2 * 4); hipMemset(B2, 0, (size_t)K2 * N2 * 4);
+      const double f2 = 2.0 * M2 * N2 * K2;
+      printf("M=%d N=%d K=%d\n", M2, N2, K2);
+      timeit("dense_f32() dispatch", [&] { dense_f32(A2, B2, bias, C2, M2, K2, N2, 0, 0); }, f2);
+      DenseArgs a{A2, B2, bias, C2, M2, N2, K2, K2, N2, N2, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};
+      auto fast = [&](auto kern, int bm, int bn, int nt, const char* nm) {
+        DenseArgs b = a; b.tiles_m = ceil_div(M2, bm); b.tiles_n = ceil_div(N2, bn); b.band_order = 0;
+        timeit(nm, [&] { hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(nt), 0, 0, b); }, f2);
+      };
+      fast(dense_f32_fast_kernel<128, 128, 4, 2, 2, 0>, 128, 128, 512, "fast 128x128 (96 tiles)");
+      fast(dense_f32_fast_kernel<64, 64, 2, 2, 2, 0>, 64, 64, 256, "fast 64x64 minw2 (384 tiles)");
+      fast(dense_f32_fast_kernel<64, 64, 2, 2, 4, 0>, 64, 64, 256, "fast 64x64 minw4 (384 tiles)");
+      fast(dense_f32_fast_kernel<128, 64, 4, 2, 2, 0>, 128, 64, 512, "fast 128x64 8 waves (192 tiles)");
+      fast(dense_f32_fast_kernel<64, 128, 2, 4, 2, 0>, 64, 128, 512, "fast 64x128 8 waves (192 tiles)");
+      fast(dense_f32_fast_kernel<128, 64, 4, 1, 2, 0>, 128, 64, 256, "fast 128x64 4 waves (192 tiles)");
+      fast(dense_f32_fast_kernel<64, 64, 2, 1, 4, 0>, 64, 64, 128, "fast 64x64 2 waves (384 tiles)");
+    }
+  }
   return 0;
 }
