@@ -180,3 +180,24 @@ def test_searcher_with_plain_callable_network():
     tok_o = co.baseline_sequence_beam_search(p, feats, seqs, 3, dims["V"], 0, 3, 4, 0)
     got = BaselineSequeneBeamSearcher(Plain(), 3, dims["V"], 0, 3, 4)(to_dev(feats), to_dev(seqs))
     np.testing.assert_array_equal(np_of(got), tok_o)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32_split"])
+@pytest.mark.parametrize("max_length", [7, 0])
+def test_search_baseline_fused_masks_match_the_mask_kernel(precision, max_length):
+    """The logit masks applied inside the projection's top-k epilogue (every precision has
+    its own projection kernel) against the in-place mask kernel + unfused beam step: the same
+    beam records at every step."""
+    dims = dict(F=64, D=64, E=64, H=64, V=512)
+    p = _params(11, dims, "lstm", bias_seed=12)
+    rng = np.random.default_rng(13)
+    B, L, W, T = 6, 5, 3, 9
+    feats = np.abs(rng.standard_normal((B, L, dims["D"]))).astype(np.float32)
+    seqs = _sequences(rng, B, T)
+    tok_f, tr_f = _engine_search(p, feats, seqs, W, max_length, dims, "lstm", True, precision)
+    tok_u, tr_u = _engine_search(p, feats, seqs, W, max_length, dims, "lstm", False, precision)
+    np.testing.assert_array_equal(tok_f, tok_u)
+    np.testing.assert_array_equal(np_of(tr_f["ids"]), np_of(tr_u["ids"]))
+    np.testing.assert_array_equal(np_of(tr_f["parents"]), np_of(tr_u["parents"]))
+    lf, lu = np_of(tr_f["log_probs"]), np_of(tr_u["log_probs"])
+    np.testing.assert_allclose(np.maximum(lf, -1e30), np.maximum(lu, -1e30), rtol=1e-5, atol=1e-6)
