@@ -90,6 +90,7 @@ SIGNATURES = {
                             _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_lstm_step_f32": ([_P] * 12 + [_I] * 5 + [_P], C.c_int),
     "icap_gru_pack_f32": ([_P] * 6 + [_I] * 2 + [_P], C.c_int),
+    "icap_gru_step_bf16": ([_P] * 7 + [_I] * 4 + [_P], C.c_int),
     "icap_gru_step_f32": ([_P] * 10 + [_I] * 5 + [_P], C.c_int),
     "icap_beam_step_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                             _I, _I, _I, _P, C.c_size_t, _P], C.c_int),

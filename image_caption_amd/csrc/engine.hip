@@ -42,6 +42,8 @@ int pack_weight_bf16(const float*, void*, int, int, int, int, int, hipStream_t);
 int dense_bf16(const float*, const void*, const float*, float*, int, int, int, int, hipStream_t);
 int lstm_step_bf16(const float*, const float*, const float*, const void*, const float*, const float*,
                    const int32_t*, float*, float*, int, int, int, int, hipStream_t);
+int gru_step_bf16(const float*, const float*, const void*, const float*, const float*, const int32_t*,
+                  float*, int, int, int, int, hipStream_t);
 int dense_topk_half_tiles(int N);
 int dense_topk_record_floats(int top_k);
 bool dense_topk_supported(const float*, const float*, int, int, int, int);
@@ -159,8 +161,6 @@ int check_config(const icap_config& c) {
                "engine: unknown tile_mode %d", c.tile_mode);
   ICAP_REQUIRE(c.U % 4 == 0 && c.D % 4 == 0, "engine: U and D must be multiples of 4");
   ICAP_REQUIRE(c.cell == ICAP_CELL_LSTM || c.cell == ICAP_CELL_GRU, "engine: unknown cell %d", c.cell);
-  if (c.cell == ICAP_CELL_GRU && c.precision == ICAP_PRECISION_BF16)
-    return fail(ICAP_ERR_UNSUPPORTED, "engine: the GRU cell is built for fp32 and fp32 split mode");
   if (c.precision != ICAP_PRECISION_FP32 && c.precision != ICAP_PRECISION_BF16 &&
       c.precision != ICAP_PRECISION_F32_SPLIT)
     return fail(ICAP_ERR_UNSUPPORTED, "engine: precision %d is not built", c.precision);
@@ -311,7 +311,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     if (t > 0 && e->overlap) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
     {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
-      if (gru)
+      if (gru && c.precision == ICAP_PRECISION_BF16)
+        ICAP_TRY(gru_step_bf16(e->ctx, e->h[cur], e->pk[icap_engine::PK_LSTM], e->cell_bias,
+                               e->emb_proj, ids, e->h[cur ^ 1], N, c.D, c.H, c.V, s));
+      else if (gru)
         ICAP_TRY(gru_step_f32(e->ctx, nullptr, w.embedding, ids, e->emb_proj, e->h[cur],
                               e->cell_kernel, e->cell_recurrent, e->cell_bias, e->h[cur ^ 1], N, c.D,
                               c.E, c.H, c.V, s));
@@ -399,7 +402,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 106; }
+int icap_version(void) { return 107; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -500,6 +503,12 @@ int icap_gru_pack_f32(const float* kernel, const float* recurrent_kernel, const 
                       icap_stream_t stream) {
   return gru_pack_f32(kernel, recurrent_kernel, bias, kernel4, recurrent4, bias4, CE, H,
                       (hipStream_t)stream);
+}
+
+int icap_gru_step_bf16(const float* ctx, const float* h, const void* packed_w, const float* bias4,
+                       const float* emb_proj, const int32_t* ids, float* h_out, int N, int C, int H,
+                       int V, icap_stream_t stream) {
+  return gru_step_bf16(ctx, h, packed_w, bias4, emb_proj, ids, h_out, N, C, H, V, (hipStream_t)stream);
 }
 
 int icap_gru_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,

@@ -42,6 +42,7 @@ struct Bf16Args {
   const float* emb_proj;  // [V,4H] token-only gate pre-activations, may be null
   const int32_t* ids;
   int H, V;
+  int gru;  // cell update: 0 LSTM (i, f, g, o), 1 GRU on four-column operands (z, r, x_h, rec_h)
   // top-k epilogue (dense_topk_bf16): per (row, 64 columns) records instead of y
   float* rec;
   float* eos_x;
@@ -236,9 +237,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
         for (int g = 0; g < 4; ++g) z[g] += ep[g * H];
       }
       const size_t o = (size_t)m * H + unit;
-      const float cn = fast_sigmoid(z[1]) * p.c_in[o] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
-      p.c_out[o] = cn;
-      p.h_out[o] = fast_sigmoid(z[3]) * fast_tanh(cn);
+      if (p.gru) {
+        const float zg = fast_sigmoid(z[0]), rg = fast_sigmoid(z[1]);
+        const float hh = fast_tanh(z[2] + rg * z[3]);
+        p.h_out[o] = zg * p.a1[o] + (1.f - zg) * hh;   // a1 is the previous state h [N,H]
+      } else {
+        const float cn = fast_sigmoid(z[1]) * p.c_in[o] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
+        p.c_out[o] = cn;
+        p.h_out[o] = fast_sigmoid(z[3]) * fast_tanh(cn);
+      }
     }
   }
 }
@@ -342,10 +349,33 @@ int dense_topk_bf16(const float* x, const void* packed_w, const float* bias, int
   return ICAP_OK;
 }
 
+namespace {
+int cell_step_bf16(int gru, const float* ctx, const float* h, const float* c, const void* packed_w,
+                   const float* bias, const float* emb_proj, const int32_t* ids, float* h_out,
+                   float* c_out, int N, int C, int H, int V, hipStream_t s);
+}
+
 int lstm_step_bf16(const float* ctx, const float* h, const float* c, const void* packed_w,
                    const float* bias, const float* emb_proj, const int32_t* ids, float* h_out,
                    float* c_out, int N, int C, int H, int V, hipStream_t s) {
-  ICAP_REQUIRE(ctx && h && c && packed_w && h_out && c_out, "lstm_step_bf16: null pointer");
+  ICAP_REQUIRE(c && c_out, "lstm_step_bf16: null pointer");
+  return cell_step_bf16(0, ctx, h, c, packed_w, bias, emb_proj, ids, h_out, c_out, N, C, H, V, s);
+}
+
+// GRU step with bf16 operands: packed_w holds the four-column operands of icap_gru_pack_f32
+// (kernel4[0:C] then recurrent4, gates interleaved), bias4 in [4H] order.
+int gru_step_bf16(const float* ctx, const float* h, const void* packed_w, const float* bias4,
+                  const float* emb_proj, const int32_t* ids, float* h_out, int N, int C, int H, int V,
+                  hipStream_t s) {
+  return cell_step_bf16(1, ctx, h, nullptr, packed_w, bias4, emb_proj, ids, h_out, nullptr, N, C, H, V,
+                        s);
+}
+
+namespace {
+int cell_step_bf16(int gru, const float* ctx, const float* h, const float* c, const void* packed_w,
+                   const float* bias, const float* emb_proj, const int32_t* ids, float* h_out,
+                   float* c_out, int N, int C, int H, int V, hipStream_t s) {
+  ICAP_REQUIRE(ctx && h && packed_w && h_out, "lstm_step_bf16: null pointer");
   ICAP_REQUIRE(N > 0 && C > 0 && H > 0, "lstm_step_bf16: bad shape");
   ICAP_REQUIRE(C % BK == 0 && H % BK == 0, "lstm_step_bf16: C=%d and H=%d must be multiples of %d", C,
                H, BK);
@@ -360,7 +390,9 @@ int lstm_step_bf16(const float* ctx, const float* h, const float* c, const void*
   a.w = static_cast<const uint16_t*>(packed_w);
   a.bias = bias; a.y = nullptr; a.M = N; a.N = 4 * H; a.K = C + H; a.act = ICAP_ACT_NONE;
   a.c_in = c; a.h_out = h_out; a.c_out = c_out; a.emb_proj = emb_proj; a.ids = ids; a.H = H; a.V = V;
+  a.gru = gru;
   return launch<64, true>(a, s, "gemm_bf16_kernel<lstm>");
 }
+}  // namespace
 
 }  // namespace icap

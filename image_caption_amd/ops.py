@@ -410,6 +410,22 @@ def lstm_step_bf16(ctx, h, c, packed, bias, emb_proj=None, ids=None):
     return h_out, c_out
 
 
+def gru_step_bf16(ctx, h, packed, bias4, emb_proj=None, ids=None):
+    """One GRU cell step on [ctx | h] with bf16 operands; `packed` holds the four-column
+    operands of gru_pack (kernel4[0:C] then recurrent4) with interleaved gates
+    (PackedWeight(C + H, 4H, gate_units=H)); returns h'."""
+    N, C = ctx.shape
+    H = h.shape[-1]
+    if packed.K != C + H or packed.N != 4 * H or packed.gate_units != H:
+        raise ValueError("gru_step_bf16: packed weight does not match C=%d H=%d" % (C, H))
+    h_out = torch.empty_like(h)
+    V = emb_proj.shape[0] if emb_proj is not None else 0
+    _lib.call("icap_gru_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), packed.buf.data_ptr(),
+              _opt(bias4, f32, "bias4"), _opt(emb_proj, f32, "emb_proj"), _opt(ids, i32, "ids"),
+              h_out.data_ptr(), N, C, H, V, current_stream())
+    return h_out
+
+
 # ---- fused vocab projection + beam step ----------------------------------------------
 
 def dense_topk(x, kernel, bias, eos_token, top_k):

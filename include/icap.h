@@ -163,6 +163,12 @@ int icap_lstm_step_bf16(const float* ctx, const float* h, const float* c,
                         const void* packed_w, const float* bias, const float* emb_proj,
                         const int32_t* ids, float* h_out, float* c_out,
                         int N, int C, int H, int V, icap_stream_t stream);
+/* GRU step with bf16 operands: packed_w = icap_pack_weight_bf16 of the four-column operands
+ * of icap_gru_pack_f32 (kernel4 rows [0,C), then recurrent4, gate_units = H), bias4 [4H].
+ * Same cell arithmetic as icap_gru_step_f32 (decoder/recurrent_decoder.py:97-99). */
+int icap_gru_step_bf16(const float* ctx, const float* h, const void* packed_w, const float* bias4,
+                       const float* emb_proj, const int32_t* ids, float* h_out,
+                       int N, int C, int H, int V, icap_stream_t stream);
 
 /* ---- split mode (ICAP_PRECISION_F32_SPLIT) -----------------------------------------
  * Same contractions with fp32 accuracy at 6/16 of the exact-f32 matrix-pipe time: an fp32
