@@ -684,12 +684,17 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     }
   }
   if (err == hipSuccess) {
-    // beside the vocab projection the attention kernel gets one workgroup per compute unit
-    // (tuning knob ICAP_SIDE_ATT_WGS: 0 = uncapped)
+    // beside the exact-f32 vocab projection the attention kernel gets one workgroup per
+    // compute unit, which leaves the projection its two workgroups per CU (96.8k captions/s
+    // against 92.7k uncapped at the headline shape).  The bf16 projection is short enough
+    // that a capped attention becomes the critical path (114k capped, 129k uncapped at
+    // B=512, W=5), so it runs uncapped there.  Tuning knob ICAP_SIDE_ATT_WGS: 0 = uncapped.
     hipDeviceProp_t prop;
     err = hipGetDeviceProperties(&prop, e->device);
     static const char* cap_env = getenv("ICAP_SIDE_ATT_WGS");
-    if (err == hipSuccess) e->side_att_wgs = cap_env ? atoi(cap_env) : prop.multiProcessorCount;
+    if (err == hipSuccess)
+      e->side_att_wgs = cap_env ? atoi(cap_env)
+                                : (c.precision == ICAP_PRECISION_BF16 ? 0 : prop.multiProcessorCount);
   }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
