@@ -677,15 +677,21 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
     ci[NCAND - 1] = fi;
   }
 
-  // ---- W rounds of workgroup-wide argmax; a winner is retired by its owner ----
+  // ---- W rounds of workgroup-wide argmax ----
+  // Every thread keeps the best of its remaining candidates; a round compares those (one
+  // value per thread), and only the winner's owner retires it and rescans its own list
+  // (flat indices are unique: the eos column and finished rows are scored by the special
+  // candidates only).
+  float lb_s = cs[0], lb_t = ct[0];
+  int lb_i = ci[0];
+#pragma unroll
+  for (int q = 1; q < NCAND; ++q)
+    if (cand_better(cs[q], ci[q], lb_s, lb_i)) { lb_s = cs[q]; lb_t = ct[q]; lb_i = ci[q]; }
   float my_s = -INFINITY, my_t = 0.f;
   int my_i = EMPTY_IDX;
   for (int r = 0; r < W; ++r) {
-    float bs = cs[0], bt = ct[0];
-    int bi = ci[0];
-#pragma unroll
-    for (int q = 1; q < NCAND; ++q)
-      if (cand_better(cs[q], ci[q], bs, bi)) { bs = cs[q]; bt = ct[q]; bi = ci[q]; }
+    float bs = lb_s, bt = lb_t;
+    int bi = lb_i;
     wave_best(bs, bt, bi);
     if (lane == 0) { s_bs[wave] = bs; s_bt[wave] = bt; s_bi[wave] = bi; }
     __syncthreads();
@@ -694,9 +700,14 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
     for (int q = 1; q < NWV; ++q)
       if (cand_better(s_bs[q], s_bi[q], bs, bi)) { bs = s_bs[q]; bt = s_bt[q]; bi = s_bi[q]; }
     __syncthreads();
+    if (lb_i == bi && bi != EMPTY_IDX) {
+      lb_s = -INFINITY; lb_t = 0.f; lb_i = EMPTY_IDX;
 #pragma unroll
-    for (int q = 0; q < NCAND; ++q)
-      if (ci[q] == bi && bi != EMPTY_IDX) { cs[q] = -INFINITY; ci[q] = EMPTY_IDX; }
+      for (int q = 0; q < NCAND; ++q) {
+        if (ci[q] == bi) { cs[q] = -INFINITY; ci[q] = EMPTY_IDX; }
+        if (cand_better(cs[q], ci[q], lb_s, lb_i)) { lb_s = cs[q]; lb_t = ct[q]; lb_i = ci[q]; }
+      }
+    }
     if (tid == r) { my_s = bs; my_t = bt; my_i = bi; }
   }
 
