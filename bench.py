@@ -341,6 +341,10 @@ def main():
         n_vocab = vocab_n
         avg_s = vocab_ms / max(vocab_n, 1) * 1e-3
         flops = 2.0 * N * cfg["H"] * cfg["V"]
+        if precision == "fp32" and eng.fused_vocab and loop == "decode" and cfg["W"] > 1:
+            # the time-0 launch of a decode projects beam 0 only (B rows instead of B*W):
+            # algorithmic flops per launch, averaged over the T launches of a decode
+            flops = 2.0 * cfg["H"] * cfg["V"] * (N * (cfg["T"] - 1) + cfg["B"]) / cfg["T"]
         if precision == "bf16" and not eng.fused_vocab:
             vbytes = cfg["H"] * cfg["V"] * 2.0 + N * cfg["H"] * 4.0 + N * cfg["V"] * 4.0
             achieved = vbytes / avg_s / 1e9 if avg_s > 0 else 0.0

@@ -521,9 +521,10 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
 //      pick the successors; threads 0..W-1 then write the outputs and the next state.
 // A row's best W are always among its half tiles' best WL >= W, so nothing is lost.
 struct RecArgs {
-  const float* rec;    // [B*W][HT][2 + 2*WL]
-  const float* eos_x;  // [B*W]
+  const float* rec;    // [B*rpi][HT][2 + 2*WL]
+  const float* eos_x;  // [B*rpi]
   int HT;
+  int rpi;             // record rows per image: W, or 1 when only beam 0 was projected (time 0)
   const float* log_probs;
   const uint8_t* finished;
   const int32_t* lengths;
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
     const bool ok = idx < n_rec;
     const int cl = ok ? idx : 0;
     rrow[it] = ok ? cl / HT : -1;
-    const float4* src = reinterpret_cast<const float4*>(p.rec + (row0 * HT + cl) * RL);
+    const float4* src = reinterpret_cast<const float4*>(p.rec + ((size_t)b * p.rpi * HT + cl) * RL);
 #pragma unroll
     for (int q = 0; q < RL / 4; ++q) rr[it][q] = src[q];
   }
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
   }
   const int sp_w = tid / (W + 2), sp_j = tid - sp_w * (W + 2);
   const bool sp_on = sp_w < n_rows;
-  const float sp_eos_x = p.eos_x[row0 + (sp_on ? sp_w : 0)];
+  const float sp_eos_x = p.eos_x[(size_t)b * p.rpi + (sp_on ? sp_w : 0)];
 
   // ---- row statistics: (max, sum exp) folded per thread, per wave, then per workgroup ----
   float Mw[MAXW], Lw[MAXW];
@@ -857,7 +858,7 @@ int beam_step_from_records_f32(const float* records, const float* eos_logit, int
                                double length_penalty_weight, float* scores,
                                int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
                                uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
-                               hipStream_t s) {
+                               hipStream_t s, int compact_first) {
   ICAP_REQUIRE(records && eos_logit && log_probs && finished && lengths,
                "beam_step_from_records_f32: null input");
   ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
@@ -874,6 +875,9 @@ int beam_step_from_records_f32(const float* records, const float* eos_logit, int
                half_tiles);
   RecArgs a;
   a.rec = records; a.eos_x = eos_logit; a.HT = half_tiles;
+  ICAP_REQUIRE(!compact_first || time <= 0,
+               "beam_step_from_records_f32: one record row per image only serves time 0");
+  a.rpi = compact_first ? 1 : W;
   a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
   a.time = time; a.eos = eos_token;
   a.scores = scores; a.ids = predicted_ids; a.parents = parent_ids;

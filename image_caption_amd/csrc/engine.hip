@@ -65,7 +65,11 @@ int dense_topk_bf16(const float*, const void*, const float*, int, int, int, int,
                     const LogitMasks*, hipStream_t);
 int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
                                const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
-                               uint8_t*, int32_t*, int, int, int, hipStream_t);
+                               uint8_t*, int32_t*, int, int, int, hipStream_t, int compact_first = 0);
+int dense_f32_strided(const float*, int, const float*, const float*, float*, int, int, int, int,
+                      hipStream_t);
+int dense_topk_f32_strided(const float*, int, const float*, const float*, int, int, int, int, int,
+                           float*, float*, const LogitMasks*, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, int, hipStream_t);
@@ -337,15 +341,36 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(attention_step(e->side, gru ? e->h[cur] : e->c));
       ICAP_HIP(hipEventRecord(e->ev_att, e->side));
     }
+    const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
+    const int bs_time = t + lv.time_offset;  // the beam step ranks beam 0 only at time 0
+    masks.step1 = bs_time + 1;
+    const LogitMasks* mk = masks.any() ? &masks : nullptr;
+    if (e->topk && bs_time == 0 && c.W > 1 && c.precision == ICAP_PRECISION_FP32 && !mk) {
+      // Time 0 ranks the candidates of beam 0 only (beam_search.py:451-455), so fc1 and the
+      // vocab projection run on every W-th row (row stride W*H) and write one record row per
+      // image; the recurrent state of all rows was still advanced above.
+      {
+        Timed tm(e, ICAP_K_FC1, s);
+        ICAP_TRY(dense_f32_strided(e->h[cur], c.W * c.H, w.fc1_kernel, w.fc1_bias, e->fc1o, c.B, c.H,
+                                   c.H, ICAP_ACT_NONE, s));
+      }
+      {
+        Timed tm(e, ICAP_K_VOCAB, s);
+        ICAP_TRY(dense_topk_f32_strided(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V,
+                                        c.eos_id, e->topk, e->rec, e->eos_x, nullptr, s));
+      }
+      Timed tm(e, ICAP_K_BEAM, s);
+      ICAP_TRY(beam_step_from_records_f32(
+          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, 0, c.eos_id,
+          c.length_penalty_weight, e->hist_scores, e->hist_ids, e->hist_parents, e->hist_lp, e->fin,
+          e->len, c.B, c.W, c.V, s, 1));
+      continue;
+    }
     {  // K7: fc1
       Timed tm(e, ICAP_K_FC1, s);
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
                             c.H, c.H, ICAP_ACT_NONE, s));
     }
-    const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
-    const int bs_time = t + lv.time_offset;  // the beam step ranks beam 0 only at time 0
-    masks.step1 = bs_time + 1;
-    const LogitMasks* mk = masks.any() ? &masks : nullptr;
     if (e->topk) {
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
       {

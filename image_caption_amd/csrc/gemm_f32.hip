@@ -1079,14 +1079,24 @@ int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
 
 }  // namespace
 
+int dense_f32_strided(const float* x, int lda, const float* w, const float* bias, float* y, int M,
+                      int K, int N, int act, hipStream_t s);
+
 int dense_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
               int act, hipStream_t s) {
+  return dense_f32_strided(x, K, w, bias, y, M, K, N, act, s);
+}
+
+// x rows lda floats apart (lda >= K): e.g. every W-th row of a [B*W,K] matrix with lda = W*K.
+int dense_f32_strided(const float* x, int lda, const float* w, const float* bias, float* y, int M,
+                      int K, int N, int act, hipStream_t s) {
   ICAP_REQUIRE(x && w && y, "dense_f32: null pointer");
+  ICAP_REQUIRE(lda >= K && lda % 4 == K % 4, "dense_f32: bad row stride %d for K = %d", lda, K);
   ICAP_REQUIRE(M > 0 && K > 0 && N > 0, "dense_f32: M, K, N must be positive (got %d, %d, %d)", M,
                K, N);
   ICAP_REQUIRE(act == ICAP_ACT_NONE || act == ICAP_ACT_RELU, "dense_f32: unknown activation %d",
                act);
-  DenseArgs a{x, w, bias, y, M, N, K, K, N, N, act, 0, 0, 0, nullptr, nullptr, -1};
+  DenseArgs a{x, w, bias, y, M, N, K, lda, N, N, act, 0, 0, 0, nullptr, nullptr, -1};
   {
     // Tile order (tuning knob ICAP_TILE_ORDER=col|band overrides): a band of panels per XCD
     // when the A operand is too large to stay in one 4 MB L2 next to a B panel.
@@ -1110,7 +1120,7 @@ int dense_f32(const float* x, const float* w, const float* bias, float* y, int M
     if (vec && K >= 1024 && K % BK == 0 && tiles64 > 128 && tiles64 <= 512 && !ks_env)
       return launch_dense<64, 128, 2, 4, 2>(a, vec, s);
     if (ks > 1 && vec && K % 64 == 0 && N >= 4 && tiles64 <= 512 &&
-        (long long)M * K < (1LL << 31) && (long long)K * N < (1LL << 31)) {
+        (long long)M * lda < (1LL << 31) && (long long)K * N < (1LL << 31)) {
       a.tiles_m = ceil_div(M, 64);
       a.tiles_n = ceil_div(N, 64);
       // row bands per XCD when A is the larger operand (tuning knob ICAP_SMALL_ORDER=col|row)
@@ -1144,15 +1154,27 @@ bool dense_topk_supported(const float* x, const float* w, int M, int K, int N, i
          (long long)M * K < (1LL << 31) && (long long)K * N < (1LL << 31);
 }
 
+int dense_topk_f32_strided(const float* x, int lda, const float* w, const float* bias, int M, int K,
+                           int N, int eos, int top_k, float* records, float* eos_logit,
+                           const LogitMasks* masks, hipStream_t s);
+
 int dense_topk_f32(const float* x, const float* w, const float* bias, int M, int K, int N,
                    int eos, int top_k, float* records, float* eos_logit, const LogitMasks* masks,
                    hipStream_t s) {
+  return dense_topk_f32_strided(x, K, w, bias, M, K, N, eos, top_k, records, eos_logit, masks, s);
+}
+
+int dense_topk_f32_strided(const float* x, int lda, const float* w, const float* bias, int M, int K,
+                           int N, int eos, int top_k, float* records, float* eos_logit,
+                           const LogitMasks* masks, hipStream_t s) {
   ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_f32: null pointer");
+  ICAP_REQUIRE(lda >= K && lda % 4 == 0 && (long long)M * lda < (1LL << 31),
+               "dense_topk_f32: bad row stride %d", lda);
   ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k),
                "dense_topk_f32: needs top_k in {1,3,5}, K %% 32 == 0, N %% 4 == 0 and 16-byte "
                "aligned operands (M=%d K=%d N=%d top_k=%d)", M, K, N, top_k);
   ICAP_REQUIRE(aligned16(records), "dense_topk_f32: records must be 16-byte aligned");
-  DenseArgs a{x, w, bias, nullptr, M, N, K, K, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  DenseArgs a{x, w, bias, nullptr, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
   if (masks) a.masks = *masks;
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, 128);

@@ -24,7 +24,7 @@ int dense_topk_f32(const float*, const float*, const float*, int, int, int, int,
 bool beam_records_supported(int W, int half_tiles, int top_k);
 int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
                                const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
-                               uint8_t*, int32_t*, int, int, int, hipStream_t);
+                               uint8_t*, int32_t*, int, int, int, hipStream_t, int compact_first = 0);
 int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
                   double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
                   int, void*, size_t, hipStream_t);
