@@ -6,7 +6,6 @@
 #include <vector>
 #include <cmath>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 32;
 struct Args { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc, tiles_m, tiles_n; };
 
 __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -16,7 +15,7 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
 }
 // VARIANT bits: 1 = skip global loads in loop, 2 = skip MFMA, 4 = skip LDS store+barrier in loop, 8 = skip epilogue stores,
 // 16 = the library's schedule: next-step loads above the per-step barrier, staging registers pinned below the multiplies
-template <int BM, int BN, int WM, int WN, int VARIANT, int MINW>
+template <int BM, int BN, int WM, int WN, int VARIANT, int MINW, int BK = 32>
 __global__ __launch_bounds__(WM* WN * 64, MINW)
 #ifdef WPE
     __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
@@ -113,14 +112,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
   }
 }
 
-template <int BM, int BN, int WM, int WN, int VARIANT, int MINW>
+template <int BM, int BN, int WM, int WN, int VARIANT, int MINW, int BK = 32>
 float run(Args a, int iters, const char* name) {
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = a.tiles_m * a.tiles_n;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW, BK>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW, BK>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   const float us = ms * 1e3f / iters;
@@ -152,6 +151,9 @@ int main(int argc, char** argv) {
 #define S(BM,BN,WM,WN,MW) run<BM,BN,WM,WN,16,MW>(a, 20, "sched " #BM "x" #BN " waves " #WM "x" #WN " minw " #MW);
   S(128,128,4,2,2) S(128,128,2,4,2) S(128,128,4,4,2) S(256,128,4,4,1) S(128,256,4,4,1) S(128,256,2,4,1) S(256,256,4,4,1)
   S(64,128,2,4,4) S(128,64,4,2,4) S(64,64,2,2,4) S(128,128,4,2,3) S(256,128,4,2,1) S(128,256,4,2,1)
+#define SK(BM,BN,WM,WN,MW,BKK) run<BM,BN,WM,WN,16,MW,BKK>(a, 20, "sched " #BM "x" #BN " waves " #WM "x" #WN " minw " #MW " BK " #BKK);
+  SK(128,128,4,2,2,32) SK(128,128,4,2,3,16) SK(128,128,4,2,4,16) SK(128,128,4,2,2,16) SK(128,128,4,2,1,64) SK(128,128,2,2,4,16) SK(128,128,2,2,6,16) SK(128,128,2,2,3,32)
+  SK(128,128,4,2,2,32)
   run<128,128,4,2,8,2>(a, 20, "128x128 4x2 no epilogue");
   run<128,128,4,2,13,2>(a, 20, "128x128 4x2 MFMA+LDS reads only");
   run<128,128,4,2,4,2>(a, 20, "128x128 4x2 no LDS store/barrier");

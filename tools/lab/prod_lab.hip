@@ -68,5 +68,25 @@ int main() {
       fast(dense_f32_fast_kernel<64, 64, 2, 1, 4, 0>, 64, 64, 128, "fast 64x64 2 waves (384 tiles)");
     }
   }
+  {
+    const int M3 = 1536, N3 = 512, K3 = 512;
+    float *A3, *B3, *C3;
+    hipMalloc(&A3, (size_t)M3 * K3 * 4); hipMalloc(&B3, (size_t)K3 * N3 * 4); hipMalloc(&C3, (size_t)M3 * N3 * 4);
+    hipMemset(A3, 0, (size_t)M3 * K3 * 4); hipMemset(B3, 0, (size_t)K3 * N3 * 4);
+    const double f3 = 2.0 * M3 * N3 * K3;
+    printf("M=%d N=%d K=%d\n", M3, N3, K3);
+    timeit("dense_f32() dispatch (shortk)", [&] { dense_f32(A3, B3, bias, C3, M3, K3, N3, 0, 0); }, f3);
+    DenseArgs a{A3, B3, bias, C3, M3, N3, K3, K3, N3, N3, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};
+    auto fast = [&](auto kern, int bm, int bn, int nt, const char* nm) {
+      DenseArgs b = a; b.tiles_m = ceil_div(M3, bm); b.tiles_n = ceil_div(N3, bn); b.band_order = 0;
+      timeit(nm, [&] { hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(nt), 0, 0, b); }, f3);
+    };
+    fast(dense_f32_fast_kernel<64, 64, 2, 2, 2, 0>, 64, 64, 256, "fast 64x64 4 waves (192 tiles)");
+    fast(dense_f32_fast_kernel<64, 128, 2, 4, 2, 0>, 64, 128, 512, "fast 64x128 8 waves (96 tiles)");
+    fast(dense_f32_fast_kernel<128, 64, 4, 2, 2, 0>, 128, 64, 512, "fast 128x64 8 waves (96 tiles)");
+    fast(dense_f32_fast_kernel<32, 64, 1, 2, 4, 0>, 32, 64, 128, "fast 32x64 2 waves (384 tiles)");
+    fast(dense_f32_fast_kernel<64, 32, 2, 1, 4, 0>, 64, 32, 128, "fast 64x32 2 waves (384 tiles)");
+    fast(dense_f32_fast_kernel<32, 32, 1, 1, 8, 0>, 32, 32, 64, "fast 32x32 1 wave (768 tiles)");
+  }
   return 0;
 }
