@@ -201,3 +201,19 @@ def test_search_baseline_fused_masks_match_the_mask_kernel(precision, max_length
     np.testing.assert_array_equal(np_of(tr_f["parents"]), np_of(tr_u["parents"]))
     lf, lu = np_of(tr_f["log_probs"]), np_of(tr_u["log_probs"])
     np.testing.assert_allclose(np.maximum(lf, -1e30), np.maximum(lu, -1e30), rtol=1e-5, atol=1e-6)
+
+
+def test_search_baseline_full_size_headline_shape():
+    """512 feature maps, beam 3, 20 steps, V = 10000 in the target-length form: tokens against
+    the oracle (fp32 near-ties allowed on a few images, as for the decode loop)."""
+    dims = dict(F=64, D=256, E=256, H=512, V=10000)
+    p = _params(0, dims, "lstm")
+    rng = np.random.default_rng(21)
+    B, L, W, T = 512, 64, 3, 21
+    feats = co.mlp_encoder(co.make_images(22, B, L, 64), p["enc_kernel"], p["enc_bias"])
+    seqs = _sequences(rng, B, T)
+    tok_o = co.baseline_sequence_beam_search(p, feats, seqs, W, dims["V"], 0, 3, 4, 0)
+    tok_g, _ = _engine_search(p, feats, seqs, W, 0, dims, "lstm", True)
+    nbad = int((tok_g != tok_o[:, 1:]).any(axis=1).sum())
+    print("searcher full size: %d of 512 sequences differ from the oracle" % nbad)
+    assert nbad <= 51, nbad
