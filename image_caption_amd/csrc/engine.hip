@@ -674,7 +674,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const bool shape_ok =
         c.W <= 5 && gemm_ok && beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
     e->topk_able = shape_ok ? tk : 0;
-    e->topk = (fused_env && fused_env[0] == '0') ? 0 : e->topk_able;
+    // With fewer 128x128 tiles than compute units (small B*W) the projection is a weight
+    // stream, not a matrix-pipe problem: the short-K kernel plus the unfused beam step is
+    // faster there (B=32 greedy: 16.8k against 14.1k captions/s), so fused is the default
+    // from one tile per CU upwards.
+    const long tiles128 = (long)ceil_div((int)N, 128) * ceil_div(c.V, 128);
+    const bool fused_default = tiles128 >= 256;
+    e->topk = fused_env ? (fused_env[0] == '0' ? 0 : e->topk_able)
+                        : (fused_default ? e->topk_able : 0);
   }
   const size_t o_rec = cv.take<float>(e->topk_able ? N * dense_topk_half_tiles(c.V) *
                                                          dense_topk_record_floats(e->topk_able)

@@ -45,3 +45,14 @@ def round_bf16(x):
     u = x.view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
     return u.astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
+def prefer_fused(eng):
+    """Select the fused projection + beam step where the engine's shape is served (small
+    batches default to the unfused kernels); returns whether it is on."""
+    from image_caption_amd._lib import IcapError
+    try:
+        eng.set_fused_vocab(True)
+    except IcapError:
+        pass
+    return eng.fused_vocab

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import caption_oracle as co
-from tests.helpers import assert_close, np_of, round_bf16, to_dev
+from tests.helpers import assert_close, np_of, round_bf16, to_dev, prefer_fused
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +89,7 @@ def _decode_pair(B, W, T, dims, seed, precision):
                         length_penalty_weight=1.0, reset_state_from_feat=1, tile_mode="reference",
                         precision=precision)
     eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+    prefer_fused(eng)
     tokens, best = eng.decode(to_dev(img))
     tr = eng.trace()
     return p, img, np_of(tokens), np_of(best), {k: np_of(v) for k, v in tr.items()}
@@ -161,6 +162,7 @@ def test_engine_bf16_fused_and_unfused_vocab_paths_agree():
     cfg = CaptionConfig(B=10, W=5, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=8, start_id=3,
                         eos_id=4, precision="bf16")
     eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+    eng.set_fused_vocab(True)
     assert eng.fused_vocab
     outs = []
     for on in (True, False):

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import caption_oracle as co
-from tests.helpers import assert_close, dev, np_of, to_dev
+from tests.helpers import assert_close, dev, np_of, prefer_fused, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -129,6 +129,7 @@ def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, l
                         U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
                         length_penalty_weight=lpw, tile_mode=tile_mode, **cfg_kw)
     eng = CaptionEngine(cfg, p, device=dev())
+    prefer_fused(eng)
     tok_g, _ = eng.decode(to_dev(img))
     tr_g = eng.trace()
     tok_g = np_of(tok_g)
@@ -227,7 +228,7 @@ def test_fused_and_unfused_vocab_paths_agree():
     cfg = CaptionConfig(B=12, W=3, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=10, start_id=3,
                         eos_id=4)
     eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
-    assert eng.fused_vocab                       # this shape qualifies for the fused path
+    assert prefer_fused(eng)                     # this shape qualifies for the fused path
     outs = []
     for on in (True, False):
         eng.set_fused_vocab(on)
@@ -300,3 +301,21 @@ def test_decode_full_size_is_permutation_equivariant():
         if len(ends):
             assert (tok_a[b, ends[0]:] == 4).all()
     eng.close()
+
+
+def test_fused_path_is_the_default_from_one_tile_per_cu_upwards():
+    """Small batches (fewer 128x128 projection tiles than compute units) default to the
+    short-K projection + unfused beam step, the headline shape to the fused path; both can be
+    selected explicitly and give the same records (test_fused_and_unfused_vocab_paths_agree)."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = co.make_params(0, **PROD)
+    small = CaptionEngine(CaptionConfig(B=32, W=1, L=64, F=PROD["F"], D=PROD["D"], E=PROD["E"],
+                                        H=PROD["H"], U=PROD["H"], V=PROD["V"], T=2), p, device=dev())
+    assert not small.fused_vocab
+    small.set_fused_vocab(True)
+    assert small.fused_vocab
+    small.close()
+    big = CaptionEngine(CaptionConfig(B=512, W=3, L=64, F=PROD["F"], D=PROD["D"], E=PROD["E"],
+                                      H=PROD["H"], U=PROD["H"], V=PROD["V"], T=2), p, device=dev())
+    assert big.fused_vocab
+    big.close()

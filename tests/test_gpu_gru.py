@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import caption_oracle as co
-from tests.helpers import assert_close, dev, np_of, to_dev
+from tests.helpers import assert_close, dev, np_of, prefer_fused, to_dev
 from tests.test_gpu_e2e import SMALL, _first_divergence, _oracle_margin
 
 pytestmark = pytest.mark.gpu
@@ -125,6 +125,7 @@ def _compare_gru_decode(dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1
                         U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
                         length_penalty_weight=lpw, tile_mode=tile_mode, cell="gru", **cfg_kw)
     eng = CaptionEngine(cfg, p, device=dev())
+    prefer_fused(eng)
     tok_g, _ = eng.decode(to_dev(img))
     tr_g = eng.trace()
     tok_g = np_of(tok_g)

@@ -73,8 +73,7 @@ def _engine_search(p, feats, seqs, W, max_length, dims, cell, fused, precision="
                         T=steps, start_id=3, eos_id=4, length_penalty_weight=1.0,
                         tile_mode="reference", cell=cell, precision=precision)
     eng = CaptionEngine(cfg, q, device=dev())
-    if not fused:
-        eng.set_fused_vocab(False)
+    eng.set_fused_vocab(fused)
     assert eng.fused_vocab == fused
     seq_len = None
     if forced:
