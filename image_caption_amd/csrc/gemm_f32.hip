@@ -1056,6 +1056,79 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
   }
 }
 
+// ---------------------------------------------------------------------------------
+// LSTM / GRU step for small batches (a few dozen rows): the gate product is a weight
+// stream, and with so few 32-row patches the K loop of the tiled kernels is a chain of
+// exposed memory latencies on a handful of compute units.  Here a workgroup of 16 waves
+// owns 32 rows x 8 units (one 32-column MFMA block = 4 gates x 8 units), so even 32 rows
+// spread over H/8 compute units; wave q multiplies the q-th sixteenth of K, operands go
+// from global memory straight into the MFMA registers (lane = row / column, its half-wave
+// picks 4 of the 8 k values of a group) with all of a wave's loads in flight before its
+// multiplies; the sixteen partial blocks meet in LDS for the cell update.  Token part from
+// emb_proj rows.  Requires C % 4 == 0, (C + H) % 128 == 0, H % 8 == 0, aligned operands.
+// ---------------------------------------------------------------------------------
+template <int CELL, int NG>
+__global__ __launch_bounds__(1024, 1) void lstm_f32_skinny_kernel(LstmArgs p) {
+  __shared__ float Zs[16][32][33];  // [K slice][row][gate*8 + unit]
+  __shared__ float Z2[32][33];
+  const int tile_m = blockIdx.x % p.tiles_m, tile_j = blockIdx.x / p.tiles_m;
+  const int m0 = tile_m * 32, j0 = tile_j * 8;
+  const int K = p.C + p.H, H4 = 4 * p.H;
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int gm = min(m0 + l31, p.N - 1);      // clamped rows are computed, never stored
+  const int col = (l31 >> 3) * p.H + j0 + (l31 & 7);
+  const int k_begin = q * (K / 16);
+
+  float4 a[NG];
+  float b[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int k = k_begin + 8 * g + 4 * half;
+    const bool in_ctx = k < p.C;  // C % 4 == 0: a 4-k slice never straddles the two sources
+    const float* ap = in_ctx ? p.ctx + (size_t)gm * p.C + k : p.h + (size_t)gm * p.H + (k - p.C);
+    a[g] = *reinterpret_cast<const float4*>(ap);
+    const float* bp = (in_ctx ? p.kernel + (size_t)k * H4 : p.recurrent + (size_t)(k - p.C) * H4) + col;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[g][s] = bp[(size_t)s * H4];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, b[g][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, b[g][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, b[g][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, b[g][3], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Zs[q][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  __syncthreads();
+  {  // thread = (row, column of the block): sum of the sixteen K slices
+    const int row = tid >> 5, c = tid & 31;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += Zs[i][row][c];
+    Z2[row][c] = sum;
+  }
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 3, u = tid & 7;
+  const int m = m0 + row, j = j0 + u;
+  if (m >= p.N) return;
+  int id = p.ids[m];
+  const bool tok = id >= 0 && id < p.V;
+  id = tok ? id : 0;
+  float z[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float e = p.emb_proj[(size_t)id * H4 + g * p.H + j];
+    z[g] = (Z2[row][g * 8 + u] + (tok ? e : 0.f)) + p.bias[g * p.H + j];
+  }
+  cell_update<CELL>(p, (size_t)m * p.H + j, z[0], z[1], z[2], z[3]);
+}
+
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
   DenseArgs p = a;
@@ -1234,6 +1307,28 @@ int cell_step_f32(const char* who, const float* ctx, const float* emb, const flo
     }
   }
   const int grid = a.tiles_m * a.tiles_j;
+  {
+    // few rows: the small-batch form (tuning knob ICAP_LSTM_FORM=narrow disables)
+    static const char* form_env2 = getenv("ICAP_LSTM_FORM");
+    const int ng = (C + H) / 128;  // groups of 8 k per wave
+    const bool can_skinny = vec && emb_proj && ids && ((C + H) % 128 == 0) && (H % 8 == 0) &&
+                            (ng == 2 || ng == 4 || ng == 6 || ng == 8 || ng == 12) &&
+                            (long long)(C + H) * 4 * H < (1LL << 31);
+    const int sk_grid = ceil_div(N, 32) * (H / 8);
+    if (can_skinny && sk_grid <= 256 && !(form_env2 && form_env2[0] == 'n')) {
+      LstmArgs w = a;
+      w.tiles_m = ceil_div(N, 32);
+      w.tiles_j = H / 8;
+      const dim3 g(sk_grid), b(1024);
+      if (ng == 2) hipLaunchKernelGGL((lstm_f32_skinny_kernel<CELL, 2>), g, b, 0, s, w);
+      else if (ng == 4) hipLaunchKernelGGL((lstm_f32_skinny_kernel<CELL, 4>), g, b, 0, s, w);
+      else if (ng == 6) hipLaunchKernelGGL((lstm_f32_skinny_kernel<CELL, 6>), g, b, 0, s, w);
+      else if (ng == 8) hipLaunchKernelGGL((lstm_f32_skinny_kernel<CELL, 8>), g, b, 0, s, w);
+      else hipLaunchKernelGGL((lstm_f32_skinny_kernel<CELL, 12>), g, b, 0, s, w);
+      ICAP_LAUNCH_CHECK("lstm_f32_skinny_kernel");
+      return ICAP_OK;
+    }
+  }
   if (vec)
     hipLaunchKernelGGL((lstm_f32_kernel<true, CELL>), dim3(grid), dim3(256), 0, s, a);
   else

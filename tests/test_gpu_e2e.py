@@ -178,7 +178,8 @@ def test_decode_medium_production_dims():
     dims = dict(F=2048, D=256, E=256, H=512, V=10000)
     nbad, explained = _compare_decode({}, dims, seed=0, B=16, L=64, T=20, W=3,
                                       tile_mode="reference")
-    assert nbad <= 1, explained
+    # (ties between the identical start rows of an image's beams: margins of 1e-7 at most)
+    assert nbad <= 2 and all(m < 2e-6 for _, _, m in explained), explained
 
 
 def test_sequence_beam_search_entry_matches_engine():
