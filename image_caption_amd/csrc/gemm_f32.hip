@@ -1129,6 +1129,54 @@ __global__ __launch_bounds__(1024, 1) void lstm_f32_skinny_kernel(LstmArgs p) {
   cell_update<CELL>(p, (size_t)m * p.H + j, z[0], z[1], z[2], z[3]);
 }
 
+// Dense layer for small batches (M up to a few dozen rows), same scheme as the small-batch
+// LSTM step: workgroup = 32 rows x 32 columns, wave q multiplies the q-th sixteenth of K with
+// all its loads in flight, the sixteen partial blocks are summed through LDS.  The weights
+// are streamed once by N/32 workgroups.  K % 128 == 0, N % 4 == 0, aligned operands.
+template <int NG>
+__global__ __launch_bounds__(1024, 1) void dense_f32_skinny_kernel(DenseArgs p) {
+  __shared__ float Zs[16][32][33];
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int gm = min(m0 + l31, p.M - 1);
+  const int col = min(n0 + l31, p.N - 1);   // clamped rows / columns are computed, never stored
+  const int k_begin = q * (p.K / 16);
+  float4 a[NG];
+  float b[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int k = k_begin + 8 * g + 4 * half;
+    a[g] = *reinterpret_cast<const float4*>(p.A + (size_t)gm * p.lda + k);
+    const float* bp = p.B + (size_t)k * p.ldb + col;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[g][s] = bp[(size_t)s * p.ldb];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, b[g][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, b[g][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, b[g][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, b[g][3], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Zs[q][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  __syncthreads();
+  const int row = tid >> 5, c = tid & 31;
+  const int m = m0 + row, n = n0 + c;
+  if (m >= p.M || n >= p.N) return;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum += Zs[i][row][c];
+  float v = sum + (p.bias ? p.bias[n] : 0.f);
+  if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
+  p.C[(size_t)m * p.ldc + n] = v;
+}
+
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
   DenseArgs p = a;
@@ -1179,6 +1227,23 @@ int dense_f32_strided(const float* x, int lda, const float* w, const float* bias
     if (order_env) a.band_order = order_env[0] == 'b' ? 1 : 0;
   }
   const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(x) && aligned16(w);
+  {
+    // a few dozen rows: the small-batch form (tuning knob ICAP_SKINNY=0 disables)
+    static const char* sk_env = getenv("ICAP_SKINNY");
+    const int ng = K / 128;
+    if (vec && M <= 64 && K % 128 == 0 && lda % 4 == 0 && (ng == 2 || ng == 4 || ng == 6 || ng == 8) &&
+        (long long)K * N < (1LL << 31) && !(sk_env && sk_env[0] == '0')) {
+      a.tiles_m = ceil_div(M, 32);
+      a.tiles_n = ceil_div(N, 32);
+      const dim3 g(a.tiles_m * a.tiles_n), b(1024);
+      if (ng == 2) hipLaunchKernelGGL(dense_f32_skinny_kernel<2>, g, b, 0, s, a);
+      else if (ng == 4) hipLaunchKernelGGL(dense_f32_skinny_kernel<4>, g, b, 0, s, a);
+      else if (ng == 6) hipLaunchKernelGGL(dense_f32_skinny_kernel<6>, g, b, 0, s, a);
+      else hipLaunchKernelGGL(dense_f32_skinny_kernel<8>, g, b, 0, s, a);
+      ICAP_LAUNCH_CHECK("dense_f32_skinny_kernel");
+      return ICAP_OK;
+    }
+  }
   // 128x128 tiles (8 waves, 32x64 per wave, 2 workgroups = 4 waves per SIMD) when they
   // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);

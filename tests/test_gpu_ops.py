@@ -20,7 +20,9 @@ def ops():
     (5, 7, 3, 0), (1, 1, 1, 1), (33, 20, 65, 1), (200, 512, 300, 0), (130, 36, 128, 1),
     (1536, 512, 2000, 0), (4096, 256, 512, 1), (96, 512, 10000, 0), (64, 2048, 256, 1),
     # few 64x64 tiles and K % 64 == 0: the split-K form (full, ragged rows, ragged columns)
-    (1536, 512, 512, 0), (100, 128, 64, 1), (70, 64, 132, 0), (512, 256, 512, 1)])
+    (1536, 512, 512, 0), (100, 128, 64, 1), (70, 64, 132, 0), (512, 256, 512, 1),
+    # a few dozen rows, K % 128 == 0: the small-batch form (ragged rows and columns too)
+    (32, 512, 512, 0), (32, 512, 10000, 0), (5, 256, 100, 1), (64, 768, 36, 0), (33, 1024, 2000, 1)])
 def test_dense(ops, M, K, N, act):
     rng = np.random.default_rng(M * 7 + K * 3 + N)
     x = rng.standard_normal((M, K)).astype(np.float32)
