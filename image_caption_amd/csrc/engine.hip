@@ -674,12 +674,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const bool shape_ok =
         c.W <= 5 && gemm_ok && beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
     e->topk_able = shape_ok ? tk : 0;
-    // With fewer 128x128 tiles than compute units (small B*W) the projection is a weight
-    // stream, not a matrix-pipe problem: the short-K kernel plus the unfused beam step is
-    // faster there (B=32 greedy: 16.8k against 14.1k captions/s), so fused is the default
-    // from one tile per CU upwards.
+    // The fused projection works in 128x128 tiles; below about three of them per compute
+    // unit the plain projection (64x64 tiles, or the small-batch form) plus the unfused beam
+    // step is faster: measured at beam 3, B = 32 / 128 / 256 / 384 / 512: 15.5k / 42k / 65k /
+    // 80k / 96k captions/s fused against 18k / 50k / 73k / 79k / 93k unfused.
     const long tiles128 = (long)ceil_div((int)N, 128) * ceil_div(c.V, 128);
-    const bool fused_default = tiles128 >= 256;
+    const bool fused_default = tiles128 >= 700;
     e->topk = fused_env ? (fused_env[0] == '0' ? 0 : e->topk_able)
                         : (fused_default ? e->topk_able : 0);
   }

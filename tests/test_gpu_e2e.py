@@ -305,7 +305,7 @@ def test_decode_full_size_is_permutation_equivariant():
 
 
 def test_fused_path_is_the_default_from_one_tile_per_cu_upwards():
-    """Small batches (fewer 128x128 projection tiles than compute units) default to the
+    """Small batches (fewer than about three 128x128 projection tiles per compute unit) default to the
     short-K projection + unfused beam step, the headline shape to the fused path; both can be
     selected explicitly and give the same records (test_fused_and_unfused_vocab_paths_agree)."""
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
