@@ -1380,7 +1380,7 @@ int cell_step_f32(const char* who, const float* ctx, const float* emb, const flo
                             (ng == 2 || ng == 4 || ng == 6 || ng == 8 || ng == 12) &&
                             (long long)(C + H) * 4 * H < (1LL << 31);
     const int sk_grid = ceil_div(N, 32) * (H / 8);
-    if (can_skinny && sk_grid <= 256 && !(form_env2 && form_env2[0] == 'n')) {
+    if (can_skinny && sk_grid <= 768 && !(form_env2 && form_env2[0] == 'n')) {
       LstmArgs w = a;
       w.tiles_m = ceil_div(N, 32);
       w.tiles_j = H / 8;
