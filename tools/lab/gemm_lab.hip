@@ -14,6 +14,7 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
   tm = sid % tiles_m; tn = sid / tiles_m;
 }
 // VARIANT bits: 1 = skip global loads in loop, 2 = skip MFMA, 4 = skip LDS store+barrier in loop, 8 = skip epilogue stores,
+// 32 = (with 16) the B tile goes from global memory straight into LDS (global_load_lds_dwordx4), only A is register-staged,
 // 16 = the library's schedule: next-step loads above the per-step barrier, staging registers pinned below the multiplies
 template <int BM, int BN, int WM, int WN, int VARIANT, int MINW, int BK = 32>
 __global__ __launch_bounds__(WM* WN * 64, MINW)
@@ -45,8 +46,54 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
   _Pragma("unroll") for (int i = 0; i < B_LD; ++i) rb[i] = *reinterpret_cast<const float4*>((b_) + off_b[i]);
 #define STORET(buf_) _Pragma("unroll") for (int i = 0; i < A_LD; ++i) { const int f = tid + i * NT; As[buf_][f % (BK / 4)][f / (BK / 4)] = ra[i]; } \
   _Pragma("unroll") for (int i = 0; i < B_LD; ++i) { const int f = tid + i * NT; *reinterpret_cast<float4*>(&Bs[buf_][f / (BN / 4)][4 * (f % (BN / 4))]) = rb[i]; }
+#define LOADA(a_) _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] = *reinterpret_cast<const float4*>((a_) + off_a[i]);
+#define STOREA(buf_) _Pragma("unroll") for (int i = 0; i < A_LD; ++i) { const int f = tid + i * NT; As[buf_][f % (BK / 4)][f / (BK / 4)] = ra[i]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLDS(src_, dst_) __builtin_amdgcn_global_load_lds((src_), (dst_), 16, 0, 0)
+#define WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define GLDS(src_, dst_) ((void)0)
+#define WAIT_VM0() ((void)0)
+#endif
+#define DIRECTB(b_, buf_) _Pragma("unroll") for (int i = 0; i < B_LD; ++i) { \
+    const int f0 = (tid & ~63) + i * NT; /* first float4 of this wave's run: 64 consecutive float4 = 2 rows */ \
+    GLDS((b_) + off_b[i], &Bs[buf_][f0 / (BN / 4)][4 * (f0 % (BN / 4))]); }
   const int nk = p.K / BK;
   const float* a_tile = p.A; const float* b_tile = p.B;
+  if (VARIANT & 32) {
+    LOADA(a_tile) DIRECTB(b_tile, 0) STOREA(0)
+    WAIT_VM0();
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      const bool more = t + 1 < nk; a_tile += more ? BK : 0; b_tile += more ? (size_t)BK * p.ldb : 0;
+      LOADA(a_tile)
+      __syncthreads();
+      DIRECTB(b_tile, buf ^ 1)
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        float4 a[TM]; float b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * g + half][(wm * TM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) b[j][s2] = Bs[buf][8 * g + 4 * half + s2][(wn * TN + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j][3], acc[i][j], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+      STOREA(buf ^ 1)
+      WAIT_VM0();
+    }
+  } else {
   LOADT(a_tile, b_tile) STORET(0) if (VARIANT & 4) { STORET(1) }
   if (!(VARIANT & 16)) __syncthreads();
   for (int t = 0; t < nk; ++t) {
@@ -87,6 +134,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
       STORET(buf ^ 1)
     } else if (!(VARIANT & 4)) { STORET(buf ^ 1) __syncthreads(); }
   }
+  }
   if (VARIANT & 8) {
     float sacc = 0.f;
 #pragma unroll
@@ -117,7 +165,7 @@ float run(Args a, int iters, const char* name) {
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = a.tiles_m * a.tiles_n;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW, BK>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
+  for (int i = 0; i < 80; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW, BK>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<BM, BN, WM, WN, VARIANT, MINW, BK>), dim3(grid), dim3(WM * WN * 64), 0, 0, a);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
@@ -154,6 +202,16 @@ int main(int argc, char** argv) {
 #define SK(BM,BN,WM,WN,MW,BKK) run<BM,BN,WM,WN,16,MW,BKK>(a, 20, "sched " #BM "x" #BN " waves " #WM "x" #WN " minw " #MW " BK " #BKK);
   SK(128,128,4,2,2,32) SK(128,128,4,2,3,16) SK(128,128,4,2,4,16) SK(128,128,4,2,2,16) SK(128,128,4,2,1,64) SK(128,128,2,2,4,16) SK(128,128,2,2,6,16) SK(128,128,2,2,3,32)
   SK(128,128,4,2,2,32)
+  {
+    run<128,128,4,2,48,2>(a, 20, "direct-B sched 128x128 4x2");
+    std::vector<float> hC2((size_t)M * N); hipMemcpy(hC2.data(), C, hC2.size() * 4, hipMemcpyDeviceToHost);
+    double me = 0; for (int t = 0; t < 400; ++t) { int r = rand() % M, c = rand() % N; double s2 = 0; for (int kk = 0; kk < K; ++kk) s2 += (double)hA[(size_t)r * K + kk] * hB[(size_t)kk * N + c]; me = fmax(me, fabs(s2 - hC2[(size_t)r * N + c])); }
+    printf("direct-B spot-check max abs err %.3e\n", me);
+    run<128,128,4,2,16,2>(a, 20, "sched 128x128 4x2 (reference)");
+    run<128,128,4,2,48,2>(a, 20, "direct-B sched 128x128 4x2");
+    run<128,128,4,4,48,2>(a, 20, "direct-B sched 128x128 4x4");
+    run<128,128,2,4,48,2>(a, 20, "direct-B sched 128x128 2x4");
+  }
   run<128,128,4,2,8,2>(a, 20, "128x128 4x2 no epilogue");
   run<128,128,4,2,13,2>(a, 20, "128x128 4x2 MFMA+LDS reads only");
   run<128,128,4,2,4,2>(a, 20, "128x128 4x2 no LDS store/barrier");
