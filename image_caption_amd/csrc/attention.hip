@@ -4,209 +4,30 @@
 // attention_f32: one workgroup per feature block ("group": one image).  The rows of
 // the group (its beams) are processed together so that PF = W1(features)+b1 and the
 // features themselves are streamed once per group and step.
-//   phase 1  score[k][l] = sum_u v[u]*tanh(PF[l][u] + q_k[u])  : each wave takes
-//            locations l = wave, wave+4, ...; a lane owns 4 consecutive u per 256-wide
-//            chunk, q_k and v stay in registers; wavefront shuffles reduce over u and
-//            the scores are staged in LDS.
-//   phase 2  softmax over l per row (one wave per row, shuffles), weights kept in LDS.
-//   phase 3  ctx[k][d] = sum_l w[k][l]*F[l][d] : waves split l, lanes own 4 d each;
-//            partial sums meet in LDS; optional sigmoid gate (beta) applied on store.
+// The three phases (scores, softmax, context) are in attention_body.h.
+#include "attention_body.h"
 #include "icap_common.h"
 
 namespace icap {
 namespace {
 
 constexpr int ATT_THREADS = 256;
-constexpr int ATT_WAVES = ATT_THREADS / 64;
-constexpr int ATT_MAX_ROWS = ICAP_MAX_BEAM_WIDTH;
 
-template <bool VEC>
-__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int i, int n) {
-  if (VEC) {
-    if (i + 3 < n) return *reinterpret_cast<const float4*>(p + i);
-    return make_float4(0.f, 0.f, 0.f, 0.f);  // VEC implies n % 4 == 0 and i % 4 == 0
-  }
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i + 0 < n) v.x = p[i + 0];
-  if (i + 1 < n) v.y = p[i + 1];
-  if (i + 2 < n) v.z = p[i + 2];
-  if (i + 3 < n) v.w = p[i + 3];
-  return v;
-}
-
-struct AttArgs {
-  const float* pf;        // [G,L,U]
-  const float* features;  // [G,L,D]
-  const float* q;         // [N,U]
-  const float* v;         // [U]
-  float bv;
-  const float* score_bias;  // [N,L] or null
-  const float* gate_state;  // [N,H] or null
-  const float* gate_w;      // [H]
-  float gate_b;
-  float* ctx;      // [N,D]
-  float* weights;  // [N,L]
-  int G, R, stride_g, stride_k, L, U, D, H;
-  int grid;  // workgroups launched (<= G)
-};
-
-// RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.
+// A workgroup walks work items blockIdx.x, blockIdx.x + gridDim.x, ... (the grid may be
+// capped, see attention_f32).
 template <int RB, int UCH, bool VEC>
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // carve: score/weight [R][L] | beta [R] (padded to 16) | partial ctx [WAVES][RB][Dpad]
-  float* s_w = reinterpret_cast<float*>(smem);
-  const int sw_elems = ((p.R * p.L + 3) / 4) * 4;
-  float* s_beta = s_w + sw_elems;
-  float* s_part = s_beta + ATT_MAX_ROWS;
-  const int dpad = ((p.D + 3) / 4) * 4;
+  attention_body<ATT_THREADS, RB, UCH, VEC>(p, smem, blockIdx.x, gridDim.x);
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-
-  float4 v4[UCH];
-#pragma unroll
-  for (int ch = 0; ch < UCH; ++ch) v4[ch] = ld4<VEC>(p.v, ch * 256 + lane * 4, p.U);
-
-  // a workgroup walks groups g, g + gridDim.x, ... (the grid may be capped, see attention_f32)
-  // and every block of RB rows of a group is its own work item: rows only share reads
-  const int n_blk = (p.R + RB - 1) / RB;
-  for (int wi = blockIdx.x; wi < p.G * n_blk; wi += gridDim.x) {
-  const int g = wi / n_blk;
-  const int kb = (wi - g * n_blk) * RB;             // first row of this work item
-  const int ke = min(kb + RB, p.R);                 // one past its last row
-  const float* pf_g = p.pf + (size_t)g * p.L * p.U;
-  const float* f_g = p.features + (size_t)g * p.L * p.D;
-
-  // beta gate per row (one wave per row)
-  for (int k = kb + wave; k < ke; k += ATT_WAVES) {
-    float beta = 1.f;
-    if (p.gate_state) {
-      const int n = g * p.stride_g + k * p.stride_k;
-      const float* cs = p.gate_state + (size_t)n * p.H;
-      float part = 0.f;
-      for (int i = lane; i < p.H; i += 64) part += cs[i] * p.gate_w[i];
-      part = wave_sum(part);
-      beta = fast_sigmoid(part + p.gate_b);
-    }
-    if (lane == 0) s_beta[k] = beta;
-  }
-
-  // ---- phase 1: scores ----
-  {
-    const int k0 = kb;
-    float4 q4[RB][UCH];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int k = min(k0 + r, ke - 1);
-      const int n = g * p.stride_g + k * p.stride_k;
-#pragma unroll
-      for (int ch = 0; ch < UCH; ++ch)
-        q4[r][ch] = ld4<VEC>(p.q + (size_t)n * p.U, ch * 256 + lane * 4, p.U);
-    }
-    for (int l = wave; l < p.L; l += ATT_WAVES) {
-      float4 x[UCH];
-#pragma unroll
-      for (int ch = 0; ch < UCH; ++ch)
-        x[ch] = ld4<VEC>(pf_g + (size_t)l * p.U, ch * 256 + lane * 4, p.U);
-      float part[RB];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        part[r] = 0.f;
-        if (k0 + r >= ke) continue;  // uniform: the last block may hold fewer rows
-        float a = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < UCH; ++ch) {
-          a += v4[ch].x * fast_tanh(x[ch].x + q4[r][ch].x);
-          a += v4[ch].y * fast_tanh(x[ch].y + q4[r][ch].y);
-          a += v4[ch].z * fast_tanh(x[ch].z + q4[r][ch].z);
-          a += v4[ch].w * fast_tanh(x[ch].w + q4[r][ch].w);
-        }
-        part[r] = wave_sum(a);
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const int k = k0 + r;
-          if (k < ke) {
-            float sc = part[r] + p.bv;
-            if (p.score_bias) {
-              const int n = g * p.stride_g + k * p.stride_k;
-              sc += p.score_bias[(size_t)n * p.L + l];
-            }
-            s_w[k * p.L + l] = sc;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: softmax over l, one wave per row ----
-  for (int k = kb + wave; k < ke; k += ATT_WAVES) {
-    float m = -INFINITY;
-    for (int l = lane; l < p.L; l += 64) m = fmaxf(m, s_w[k * p.L + l]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int l = lane; l < p.L; l += 64) {
-      const float e = fast_exp(s_w[k * p.L + l] - m);
-      s_w[k * p.L + l] = e;
-      sum += e;
-    }
-    sum = wave_sum(sum);
-    const int n = g * p.stride_g + k * p.stride_k;
-    for (int l = lane; l < p.L; l += 64) {
-      const float w = s_w[k * p.L + l] / sum;
-      s_w[k * p.L + l] = w;
-      if (p.weights) p.weights[(size_t)n * p.L + l] = w;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: context ----
-  {
-    const int k0 = kb;
-    for (int d0 = 0; d0 < p.D; d0 += 256) {
-      const int d = d0 + lane * 4;
-      float4 acc[RB];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int l = wave; l < p.L; l += ATT_WAVES) {
-        const float4 f = ld4<VEC>(f_g + (size_t)l * p.D, d, p.D);
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const float w = s_w[min(k0 + r, ke - 1) * p.L + l];
-          acc[r].x += w * f.x;
-          acc[r].y += w * f.y;
-          acc[r].z += w * f.z;
-          acc[r].w += w * f.w;
-        }
-      }
-      if (d < dpad) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-          *reinterpret_cast<float4*>(&s_part[(wave * RB + r) * dpad + d]) = acc[r];
-      }
-      __syncthreads();
-      // reduce the four wave partials; thread t owns (row r, element d0 + e)
-      const int span = min(256, p.D - d0);
-      for (int idx = tid; idx < RB * span; idx += ATT_THREADS) {
-        const int r = idx / span;
-        const int e = d0 + idx % span;
-        const int k = k0 + r;
-        if (k < ke) {
-          float sum = 0.f;
-#pragma unroll
-          for (int w = 0; w < ATT_WAVES; ++w) sum += s_part[(w * RB + r) * dpad + e];
-          const int n = g * p.stride_g + k * p.stride_k;
-          p.ctx[(size_t)n * p.D + e] = sum * s_beta[k];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  }  // groups
+// Query projection + attention in one launch (attention_fq_body), shaped to sit beside two
+// workgroups of the exact-f32 projection on every compute unit: 4 waves, at most 96 VGPRs
+// (five waves per SIMD; beam widths up to 3) and about 19 KB of LDS at the headline shape.
+template <int RB>
+__global__ __launch_bounds__(ATT_THREADS, RB <= 3 ? 5 : 4) void attention_fq_kernel(AttArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attention_fq_body<ATT_THREADS, RB, 1>(p, smem, blockIdx.x, gridDim.x);
 }
 
 template <int RB, int UCH>
@@ -293,7 +114,7 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
   ICAP_REQUIRE(!gate_state || H > 0, "attention_f32: H must be positive with a gate");
   AttArgs a{pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
             G, R, stride_g, stride_k, L, U, D, H,
-            0};
+            0, nullptr, nullptr, nullptr};
   const bool vec = (U % 4 == 0) && (D % 4 == 0) && aligned16(pf) && aligned16(features) &&
                    aligned16(q) && aligned16(v);
   // rows held in registers per pass over PF: the fewest passes, then the fewest idle slots
@@ -309,9 +130,7 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
   }
   a.grid = G * ceil_div(R, rb);  // one work item per (group, block of rb rows)
   if (max_workgroups > 0 && max_workgroups < a.grid) a.grid = max_workgroups;
-  const int dpad = ((D + 3) / 4) * 4;
-  const size_t smem =
-      sizeof(float) * ((size_t)((R * L + 3) / 4) * 4 + ATT_MAX_ROWS + (size_t)ATT_WAVES * rb * dpad);
+  const size_t smem = sizeof(float) * attention_lds_floats(ATT_THREADS, R, rb, L, D);
   ICAP_REQUIRE(smem <= 160 * 1024, "attention_f32: L*R or D too large for LDS (%zu bytes)", smem);
   switch (rb) {
     case 1: return dispatch_uch<1>(a, vec, smem, s);
@@ -320,6 +139,40 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
     case 4: return dispatch_uch<4>(a, vec, smem, s);
     default: return dispatch_uch<5>(a, vec, smem, s);
   }
+}
+
+// ctx = attention(pf, features, q = state . q_w + q_b) with the beta gate on the same state:
+// the query never reaches memory.  R <= 5 rows per group, U <= 512, U, D, H multiples of 4.
+bool attention_fq_supported(int R, int L, int U, int D, int H) {
+  return R >= 1 && R <= 5 && L >= 1 && U >= 4 && U <= 512 && U % 4 == 0 && D >= 4 && D % 4 == 0 &&
+         H >= 4 && H % 4 == 0 &&
+         sizeof(float) * attention_fq_lds_floats(ATT_THREADS, R, 1, L, U, D, H) <= 64 * 1024;
+}
+
+int attention_fq_f32(const float* pf, const float* features, const float* v, float bv,
+                     const float* state, const float* gate_w, float gate_b, const float* q_w,
+                     const float* q_b, float* ctx, int G, int R, int stride_g, int stride_k, int L,
+                     int U, int D, int H, int max_workgroups, hipStream_t s) {
+  ICAP_REQUIRE(pf && features && v && state && gate_w && q_w && ctx, "attention_fq_f32: null pointer");
+  ICAP_REQUIRE(G > 0 && attention_fq_supported(R, L, U, D, H),
+               "attention_fq_f32: shape not served (R=%d L=%d U=%d D=%d H=%d)", R, L, U, D, H);
+  ICAP_REQUIRE(aligned16(pf) && aligned16(features) && aligned16(v) && aligned16(state) &&
+                   aligned16(q_w) && aligned16(ctx),
+               "attention_fq_f32: operands must be 16-byte aligned");
+  AttArgs a{pf, features, nullptr, v, bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
+            G, R, stride_g, stride_k, L, U, D, H, G, state, q_w, q_b};
+  if (max_workgroups > 0 && max_workgroups < a.grid) a.grid = max_workgroups;
+  const size_t smem = sizeof(float) * attention_fq_lds_floats(ATT_THREADS, R, 1, L, U, D, H);
+  const dim3 grid(a.grid), block(ATT_THREADS);
+  switch (R) {
+    case 1: hipLaunchKernelGGL(attention_fq_kernel<1>, grid, block, smem, s, a); break;
+    case 2: hipLaunchKernelGGL(attention_fq_kernel<2>, grid, block, smem, s, a); break;
+    case 3: hipLaunchKernelGGL(attention_fq_kernel<3>, grid, block, smem, s, a); break;
+    case 4: hipLaunchKernelGGL(attention_fq_kernel<4>, grid, block, smem, s, a); break;
+    default: hipLaunchKernelGGL(attention_fq_kernel<5>, grid, block, smem, s, a); break;
+  }
+  ICAP_LAUNCH_CHECK("attention_fq_kernel");
+  return ICAP_OK;
 }
 
 int pool_features_f32(const float* features, const float* mask, float* pooled, int G, int L,

@@ -70,6 +70,16 @@ int dense_f32_strided(const float*, int, const float*, const float*, float*, int
                       hipStream_t);
 int dense_topk_f32_strided(const float*, int, const float*, const float*, int, int, int, int, int,
                            float*, float*, const LogitMasks*, hipStream_t);
+bool dense_topk_attention_supported(int R, int L, int U, int D, int H, int top_k);
+int dense_topk_attention_f32(const float*, int, const float*, const float*, int, int, int, int, int,
+                             float*, float*, const LogitMasks*, const float*, const float*,
+                             const float*, float, const float*, const float*, float, const float*,
+                             const float*, float*, int, int, int, int, int, int, int, int, int,
+                             hipStream_t);
+bool attention_fq_supported(int R, int L, int U, int D, int H);
+int attention_fq_f32(const float*, const float*, const float*, float, const float*, const float*,
+                     float, const float*, const float*, float*, int, int, int, int, int, int, int,
+                     int, int, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, int, hipStream_t);
@@ -132,6 +142,9 @@ struct icap_engine {
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr;
   bool overlap = true;  // false: everything on the caller's stream (clean per-kernel timing)
   int side_att_wgs = 0;  // grid cap of the attention kernel when it runs on the side stream
+  // exact-f32 fused path: the next step's query + attention ride in the first workgroups of
+  // the vocab projection's launch (one stream, no events) instead of on the side stream
+  bool merged = false;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   struct Span { int cls; hipEvent_t a, b; };
@@ -294,7 +307,21 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   //   side:        \-> query_{t+1} -> attention_{t+1} -/
   // state: the attention query and the beta gate read the LSTM cell state c
   // (lstm_recurrent_decoder.py:80) or the GRU state h (recurrent_decoder.py:77,90)
+  // Opt-in (ICAP_SIDE_FQ=1): on the side stream in exact-f32 mode the query projection is
+  // folded into the attention launch (attention_fq_f32), which keeps the query kernel from
+  // competing with fc1 for whole compute units - but the longer attention costs the vocab
+  // projection more than that saves (90k against 97.5k captions/s at the headline shape).
+  const char* fq_env = getenv("ICAP_SIDE_FQ");
+  const bool side_fq = c.precision == ICAP_PRECISION_FP32 && fq_env && fq_env[0] == '1' &&
+                       attention_fq_supported(c.W, c.L, c.U, c.D, c.H) &&
+                       aligned16(w.att_v_kernel) && aligned16(w.att_w2_kernel);
   auto attention_step = [&](hipStream_t st, const float* state) -> int {
+    if (st != s && side_fq) {  // K4+K5 in one launch
+      Timed tm(e, ICAP_K_ATTENTION, st);
+      return attention_fq_f32(e->pf, features, w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel,
+                              e->fc3_bias, w.att_w2_kernel, w.att_w2_bias, e->ctx, c.B, c.W,
+                              stride_g, stride_k, c.L, c.U, c.D, c.H, e->side_att_wgs, st);
+    }
     {  // K4: q = W2(state) + b2
       Timed tm(e, ICAP_K_ATTN_QUERY, st);
       ICAP_TRY(engine_dense(e, icap_engine::PK_W2, state, w.att_w2_kernel, w.att_w2_bias, e->q, N,
@@ -308,11 +335,25 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     }
     return ICAP_OK;
   };
+  // Exact-f32 fused path: query_{t+1} + attention_{t+1} are the first workgroups of the
+  // vocab_t launch instead (dense_topk_attention_f32), everything on the caller's stream:
+  //   main: lstm_t -> fc1_t -> [attention_{t+1} | vocab_t] -> beam_t -> lstm_{t+1} ...
+  const bool merged = e->merged && e->overlap && e->topk != 0;
+  const bool side = e->overlap && !merged;
+  const int att_blocks = e->side_att_wgs > 0 ? e->side_att_wgs : c.B;
+  auto vocab_with_attention = [&](const float* x, int lda, int rows, const LogitMasks* mk,
+                                  const float* state) -> int {
+    return dense_topk_attention_f32(x, lda, w.fc2_kernel, w.fc2_bias, rows, c.H, c.V, c.eos_id,
+                                    e->topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
+                                    e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
+                                    w.att_w2_kernel, w.att_w2_bias, e->ctx, c.B, c.W, stride_g,
+                                    stride_k, c.L, c.U, c.D, c.H, att_blocks, s);
+  };
   int cur = 0;
   ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
   for (int t = 0; t < c.T; ++t) {
     const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
-    if (t > 0 && e->overlap) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
+    if (t > 0 && side) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
     {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
       if (gru && c.precision == ICAP_PRECISION_BF16)
@@ -335,7 +376,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                                e->c, N, c.D, c.E, c.H, c.V, s));
     }
     cur ^= 1;
-    if (t + 1 < c.T && e->overlap) {
+    if (t + 1 < c.T && side) {
       ICAP_HIP(hipEventRecord(e->ev_lstm, s));
       ICAP_HIP(hipStreamWaitEvent(e->side, e->ev_lstm, 0));
       ICAP_TRY(attention_step(e->side, gru ? e->h[cur] : e->c));
@@ -356,9 +397,13 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       }
       {
         Timed tm(e, ICAP_K_VOCAB, s);
-        ICAP_TRY(dense_topk_f32_strided(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V,
-                                        c.eos_id, e->topk, e->rec, e->eos_x, nullptr, s));
+        if (merged && t + 1 < c.T)
+          ICAP_TRY(vocab_with_attention(e->fc1o, c.H, c.B, nullptr, gru ? e->h[cur] : e->c));
+        else
+          ICAP_TRY(dense_topk_f32_strided(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V,
+                                          c.eos_id, e->topk, e->rec, e->eos_x, nullptr, s));
       }
+      if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
       Timed tm(e, ICAP_K_BEAM, s);
       ICAP_TRY(beam_step_from_records_f32(
           e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, 0, c.eos_id,
@@ -381,6 +426,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         else if (c.precision == ICAP_PRECISION_F32_SPLIT)
           ICAP_TRY(dense_topk_split(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
                                     c.eos_id, e->topk, e->rec, e->eos_x, mk, s));
+        else if (merged && t + 1 < c.T)
+          ICAP_TRY(vocab_with_attention(e->fc1o, c.H, N, mk, gru ? e->h[cur] : e->c));
         else
           ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
                                   e->topk, e->rec, e->eos_x, mk, s));
@@ -727,6 +774,15 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     if (err == hipSuccess)
       e->side_att_wgs = cap_env ? atoi(cap_env)
                                 : (c.precision == ICAP_PRECISION_BF16 ? 0 : prop.multiProcessorCount);
+  }
+  {
+    // opt-in (ICAP_MERGED=1, read when the engine is created): measured slower than the side
+    // stream at the headline shape (the attention workgroups take a projection slot each)
+    const char* merged_env = getenv("ICAP_MERGED");
+    e->merged = merged_env && merged_env[0] == '1' && c.precision == ICAP_PRECISION_FP32 &&
+                e->topk_able != 0 &&
+                dense_topk_attention_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able) &&
+                aligned16(weights->att_v_kernel) && aligned16(weights->att_w2_kernel);
   }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);

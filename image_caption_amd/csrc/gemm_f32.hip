@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "attention_body.h"
 #include "icap_common.h"
 #include "topk_epilogue.h"
 
@@ -224,10 +225,26 @@ __device__ __forceinline__ float half_sum(float v, int half) {
 // the logit of column `eos` is kept aside.  A row's records over all half tiles hold what
 // the log-softmax and the top-k over the whole row need, in 2 + 2*TOPK floats per 64
 // logits, so the [M,N] logits are never written to memory.
-template <int BM, int BN, int WM, int WN, int MINW, int TOPK = 0>
-__global__ __launch_bounds__(WM* WN * 64, MINW)
-    __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
-    void dense_f32_fast_kernel(DenseArgs p) {
+// One LDS object per workgroup: the A/B staging tiles, aliased (TOPK) by the waves'
+// transposition patches.
+template <int BM, int BN, int WM, int WN, int TOPK>
+struct FastLds {
+  static constexpr int T_LD = 68;  // floats per patch row: 16-byte aligned, rows 4 banks apart
+  struct Stage {
+    float4 As[2][BK / 4][BM + 1];
+    float Bs[2][BK][BN];
+  };
+  union U {
+    Stage st;
+    float patch[TOPK > 0 ? WM * WN * 32 * T_LD : 1];
+  };
+};
+
+// The work of workgroup `block` of the grid (a kernel may give its first workgroups other
+// work and pass the rest on with their index shifted down).
+template <int BM, int BN, int WM, int WN, int TOPK>
+__device__ __forceinline__ void dense_fast_body(const DenseArgs& p, int block,
+                                                typename FastLds<BM, BN, WM, WN, TOPK>::U& lds) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -237,24 +254,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
   constexpr int A_LD = (A_F4 + NT - 1) / NT;
   constexpr int B_LD = (B_F4 + NT - 1) / NT;
   constexpr int NG = BK / 8;
-
-  // one LDS object: the A/B staging tiles, aliased (TOPK) by the waves' transposition patches
-  constexpr int T_LD = 68;  // floats per patch row: 16-byte aligned, rows 4 banks apart
-  struct Stage {
-    float4 As[2][BK / 4][BM + 1];
-    float Bs[2][BK][BN];
-  };
-  union Lds {
-    Stage st;
-    float patch[TOPK > 0 ? WM * WN * 32 * T_LD : 1];
-  };
-  __shared__ Lds lds;
+  constexpr int T_LD = FastLds<BM, BN, WM, WN, TOPK>::T_LD;
   auto& As = lds.st.As;
   auto& Bs = lds.st.Bs;
 
   int tile_m, tile_n;
-  if (p.band_order) tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
-  else tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  if (p.band_order) tile_of_block_band(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  else tile_of_block(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -439,6 +445,32 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
     rec = topk_merge_neighbour<TOPK>(rec);
     if (part == 0 && row < p.M) topk_store<TOPK>(p.rec + ((size_t)row * n_ht + ht) * RL, rec);
   }
+}
+
+template <int BM, int BN, int WM, int WN, int MINW, int TOPK = 0>
+__global__ __launch_bounds__(WM* WN * 64, MINW)
+    __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
+    void dense_f32_fast_kernel(DenseArgs p) {
+  __shared__ typename FastLds<BM, BN, WM, WN, TOPK>::U lds;
+  dense_fast_body<BM, BN, WM, WN, TOPK>(p, blockIdx.x, lds);
+}
+
+// The vocab projection with its top-k epilogue, carrying the NEXT decode step's attention
+// (with the query projection folded in) in its first `att_blocks` workgroups: that attention
+// depends only on the recurrent state the cell kernel has already written, not on this
+// projection, and its loads and transcendentals run beside the matrix pipe of the tiles on
+// the same compute units.  One launch on one stream replaces a second stream, its two
+// event dependencies per step and the separate query kernel.  att_blocks is a multiple of 8
+// so that the tile workgroups keep their XCD.
+template <int TOPK, int RB>
+__global__ __launch_bounds__(512, 4)  // (min 4 waves per SIMD: two workgroups per compute unit)
+    void dense_topk_attention_kernel(DenseArgs p, AttArgs a, int att_blocks) {
+  __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
+  if ((int)blockIdx.x < att_blocks) {
+    attention_fq_body<512, RB, (RB <= 3 ? 2 : 1)>(a, reinterpret_cast<char*>(&lds), blockIdx.x, att_blocks);
+    return;
+  }
+  dense_fast_body<128, 128, 4, 2, TOPK>(p, blockIdx.x - att_blocks, lds);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1328,6 +1360,59 @@ int dense_topk_f32_strided(const float* x, int lda, const float* w, const float*
   else
     hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 2, 5>), grid, block, 0, s, a);
   ICAP_LAUNCH_CHECK("dense_f32_fast_kernel<topk>");
+  return ICAP_OK;
+}
+
+// dense_topk_f32_strided whose launch also carries an attention step with a folded-in query
+// projection (see dense_topk_attention_kernel): rows per group R <= 5 with top_k = 1 (R = 1),
+// 3 (R <= 3) or 5, U <= 512, and the attention's LDS needs within the projection's tile buffers.
+bool dense_topk_attention_supported(int R, int L, int U, int D, int H, int top_k) {
+  if (R < 1 || R > 5 || L < 1 || U < 4 || U > 512 || U % 4 || D < 4 || D % 4 || H < 4 || H % 4)
+    return false;
+  if (top_k != (R <= 1 ? 1 : (R <= 3 ? 3 : 5))) return false;
+  return sizeof(float) * attention_fq_lds_floats(512, R, R <= 3 ? 2 : 1, L, U, D, H) <=
+         sizeof(FastLds<128, 128, 4, 2, 1>::U);
+}
+
+int dense_topk_attention_f32(const float* x, int lda, const float* w, const float* bias, int M, int K,
+                             int N, int eos, int top_k, float* records, float* eos_logit,
+                             const LogitMasks* masks, const float* pf, const float* features,
+                             const float* att_v, float att_bv, const float* state,
+                             const float* gate_w, float gate_b, const float* q_w, const float* q_b,
+                             float* ctx, int G, int R, int stride_g, int stride_k, int L, int U,
+                             int D, int H, int att_blocks, hipStream_t s) {
+  ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_attention_f32: null pointer");
+  ICAP_REQUIRE(pf && features && att_v && state && gate_w && q_w && ctx,
+               "dense_topk_attention_f32: null attention pointer");
+  ICAP_REQUIRE(lda >= K && lda % 4 == 0 && (long long)M * lda < (1LL << 31),
+               "dense_topk_attention_f32: bad row stride %d", lda);
+  ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k) && aligned16(records),
+               "dense_topk_attention_f32: projection shape not served (M=%d K=%d N=%d top_k=%d)", M,
+               K, N, top_k);
+  ICAP_REQUIRE(G > 0 && dense_topk_attention_supported(R, L, U, D, H, top_k),
+               "dense_topk_attention_f32: attention shape not served (R=%d L=%d U=%d D=%d H=%d)", R,
+               L, U, D, H);
+  ICAP_REQUIRE(aligned16(pf) && aligned16(features) && aligned16(att_v) && aligned16(q_w) &&
+                   aligned16(ctx) && aligned16(state),
+               "dense_topk_attention_f32: attention operands must be 16-byte aligned");
+  DenseArgs a{x, w, bias, nullptr, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  if (masks) a.masks = *masks;
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, 128);
+  a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
+  if (att_blocks >= 8) att_blocks &= ~7;  // the tile workgroups keep their XCD
+  AttArgs t{pf, features, nullptr, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
+            G, R, stride_g, stride_k, L, U, D, H, att_blocks, state, q_w, q_b};
+  const dim3 grid(att_blocks + a.tiles_m * a.tiles_n), block(512);
+  switch (R) {
+    case 1: hipLaunchKernelGGL((dense_topk_attention_kernel<1, 1>), grid, block, 0, s, a, t, att_blocks); break;
+    case 2: hipLaunchKernelGGL((dense_topk_attention_kernel<3, 2>), grid, block, 0, s, a, t, att_blocks); break;
+    case 3: hipLaunchKernelGGL((dense_topk_attention_kernel<3, 3>), grid, block, 0, s, a, t, att_blocks); break;
+    case 4: hipLaunchKernelGGL((dense_topk_attention_kernel<5, 4>), grid, block, 0, s, a, t, att_blocks); break;
+    default: hipLaunchKernelGGL((dense_topk_attention_kernel<5, 5>), grid, block, 0, s, a, t, att_blocks); break;
+  }
+  ICAP_LAUNCH_CHECK("dense_topk_attention_kernel");
   return ICAP_OK;
 }
 

@@ -117,7 +117,7 @@ def _oracle_margin(trace_o, t, b, W, V, eos, lpw):
     return float(gaps.min())
 
 
-def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0):
+def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0, setup=None):
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
     p = co.make_params(seed, **dims)
     if bias_seed is not None:
@@ -130,6 +130,8 @@ def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, l
                         length_penalty_weight=lpw, tile_mode=tile_mode, **cfg_kw)
     eng = CaptionEngine(cfg, p, device=dev())
     prefer_fused(eng)
+    if setup is not None:
+        setup(eng)
     tok_g, _ = eng.decode(to_dev(img))
     tr_g = eng.trace()
     tok_g = np_of(tok_g)
@@ -166,6 +168,31 @@ def test_decode_small(tile_mode, W):
     nbad, _ = _compare_decode({}, SMALL, seed=1, B=5, L=5, T=7, W=W, tile_mode=tile_mode,
                               bias_seed=9)
     assert nbad == 0
+
+
+FUSABLE = dict(F=48, D=32, E=24, H=64, V=200)     # H % 32 == 0, V % 4 == 0: the fused projection
+
+
+@pytest.mark.parametrize("W", [1, 2, 3, 5])
+@pytest.mark.parametrize("schedule", ["side", "single_stream", "merged_launch", "side_fused_query"])
+def test_decode_schedules(monkeypatch, schedule, W):
+    """The default side-stream schedule, everything on one stream, and the two opt-in forms
+    (next step's query + attention inside the vocab projection's launch; query folded into the
+    side stream's attention launch) against the oracle."""
+    if schedule == "merged_launch":
+        monkeypatch.setenv("ICAP_MERGED", "1")
+    if schedule == "side_fused_query":
+        monkeypatch.setenv("ICAP_SIDE_FQ", "1")
+
+    def setup(eng):
+        assert eng.fused_vocab
+        if schedule == "single_stream":
+            eng.set_overlap(False)
+
+    for tile_mode in ("reference", "repeat"):
+        nbad, _ = _compare_decode({}, FUSABLE, seed=11 + W, B=7, L=6, T=6, W=W, tile_mode=tile_mode,
+                                  bias_seed=5, setup=setup)
+        assert nbad == 0
 
 
 def test_decode_length_penalty_and_wide_beam():
