@@ -303,9 +303,10 @@ def main():
         step()
     sync()
     # ---- timed region: exactly `steps` steps.  The launches of the dominant kernel (the
-    # vocab projection) are bracketed by HIP events on the decode stream inside it; they
-    # feed the roofline object. ----
-    eng.set_timing(["vocab"])
+    # vocab projection) are bracketed by HIP events on the decode stream inside it - in every
+    # fourth decode, an event pair costs the stream a few microseconds per launch; they feed
+    # the roofline object. ----
+    eng.set_timing(["vocab"], every=4 if args.steps >= 8 else 1)   # a sample of the decodes
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -403,6 +404,25 @@ def main():
                             "peak_GBps": PEAK_HBM_GBS},
             "kernel_ms_per_step": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
         }
+        if world == 1 and precision == "fp32" and loop == "decode" and not args.no_cpu_baseline:
+            # informational, not `value`: the same workload with the opt-in precision modes
+            # (measured before the CPU baseline, while the GPU clocks are still up)
+            eng.close()
+            other = {}
+            for mode in ("fp32_split", "bf16"):
+                e2 = CaptionEngine(CaptionConfig(start_id=3, eos_id=4, length_penalty_weight=1.0,
+                                                 tile_mode=args.tile_mode, precision=mode, **cfg),
+                                   p, device=device)
+                for _ in range(10):
+                    e2.decode(img, out=tokens, scores=scores)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    e2.decode(img, out=tokens, scores=scores)
+                torch.cuda.synchronize()
+                other[mode + "_captions_per_s"] = round(10 * cfg["B"] / (time.perf_counter() - t1), 1)
+                e2.close()
+            line["other_precision_modes"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dict(cfg, loop=loop))
         print(json.dumps(line), flush=True)

@@ -139,6 +139,7 @@ SIGNATURES = {
     "icap_logit_masks_f32": ([_P, _I, _I, _I, _P, _I, _I, _I, _P], C.c_int),
     "icap_engine_trace": ([_P, _P, _P, _P, _P, _P], C.c_int),
     "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
+    "icap_engine_set_timing_every": ([_P, C.c_int], C.c_int),
     "icap_engine_set_overlap": ([_P, _I], C.c_int),
     "icap_engine_set_fused_vocab": ([_P, _I], C.c_int),
     "icap_engine_fused_vocab": ([_P], C.c_int),

@@ -139,7 +139,7 @@ struct icap_engine {
   float *rec = nullptr, *eos_x = nullptr;
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
-  hipEvent_t ev_lstm = nullptr, ev_att = nullptr;
+  hipEvent_t ev_lstm = nullptr, ev_att = nullptr, ev_gate = nullptr;
   bool overlap = true;  // false: everything on the caller's stream (clean per-kernel timing)
   int side_att_wgs = 0;  // grid cap of the attention kernel when it runs on the side stream
   // exact-f32 fused path: the next step's query + attention ride in the first workgroups of
@@ -147,6 +147,9 @@ struct icap_engine {
   bool merged = false;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
+  unsigned timing_mask = 0;  // the caller's selection; `timing` is it or 0, per decode call
+  int timing_every = 1;      // bracket every n-th decode call
+  long decode_calls = 0;     // since the mask was set
   struct Span { int cls; hipEvent_t a, b; };
   std::vector<Span> spans;
   size_t spans_used = 0;
@@ -256,6 +259,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const int N = c.B * c.W;
   const int BL = c.B * c.L;
   const bool gru = c.cell == ICAP_CELL_GRU;
+  e->timing = (e->decode_calls++ % e->timing_every == 0) ? e->timing_mask : 0u;
 
   const float* features = lv.features ? lv.features : e->features;
   if (!lv.features) {  // K0: features = relu(img . Wenc + benc)
@@ -315,6 +319,17 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const bool side_fq = c.precision == ICAP_PRECISION_FP32 && fq_env && fq_env[0] == '1' &&
                        attention_fq_supported(c.W, c.L, c.U, c.D, c.H) &&
                        aligned16(w.att_v_kernel) && aligned16(w.att_w2_kernel);
+  // The side stream's attention has to be resident before the vocab projection's workgroups
+  // arrive: launched after them it waits for the projection's first round of tiles and ends
+  // up on the critical path.  Its launch (behind the query kernel) and the projection's
+  // (behind fc1) are a close race, so one idle event record goes in front of the projection
+  // - a few microseconds on the main stream: 98.5k against 96.3k captions/s in exact-f32
+  // mode and 115k against 100k in split mode at the headline shape; two or three records
+  // lose it again, and the short bf16 projection loses with any (187k against 203k at beam 3).
+  // A timing bracket around the projection is such a record already.  Tuning knob
+  // ICAP_VOCAB_GATE=0|1.
+  static const char* gate_env = getenv("ICAP_VOCAB_GATE");
+  const bool vocab_gate = gate_env ? gate_env[0] == '1' : c.precision != ICAP_PRECISION_BF16;
   auto attention_step = [&](hipStream_t st, const float* state) -> int {
     if (st != s && side_fq) {  // K4+K5 in one launch
       Timed tm(e, ICAP_K_ATTENTION, st);
@@ -418,6 +433,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     }
     if (e->topk) {
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
+      if (t + 1 < c.T && side && vocab_gate && !((e->timing >> ICAP_K_VOCAB) & 1u))
+        ICAP_HIP(hipEventRecord(e->ev_gate, s));
       {
         Timed tm(e, ICAP_K_VOCAB, s);
         if (c.precision == ICAP_PRECISION_BF16)
@@ -442,6 +459,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           c.V, s));
       continue;
     }
+    if (t + 1 < c.T && side && vocab_gate && !((e->timing >> ICAP_K_VOCAB) & 1u))
+      ICAP_HIP(hipEventRecord(e->ev_gate, s));
     {  // K8: vocab projection
       Timed tm(e, ICAP_K_VOCAB, s);
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
@@ -474,7 +493,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 107; }
+int icap_version(void) { return 108; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -786,7 +805,9 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_gate, hipEventDisableTiming);
   if (err != hipSuccess) {
+    if (e->ev_gate) (void)hipEventDestroy(e->ev_gate);
     if (e->ev_att) (void)hipEventDestroy(e->ev_att);
     if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
     if (e->side) (void)hipStreamDestroy(e->side);
@@ -873,6 +894,7 @@ int icap_engine_destroy(icap_engine* e) {
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);
   }
+  if (e->ev_gate) (void)hipEventDestroy(e->ev_gate);
   if (e->ev_att) (void)hipEventDestroy(e->ev_att);
   if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
   if (e->side) (void)hipStreamDestroy(e->side);
@@ -932,8 +954,18 @@ int icap_engine_trace(const icap_engine* e, int32_t* ids, int32_t* parents, floa
 
 int icap_engine_set_timing(icap_engine* e, unsigned class_mask) {
   ICAP_REQUIRE(e, "icap_engine_set_timing: null engine");
+  e->timing_mask = class_mask;
   e->timing = class_mask;
+  e->decode_calls = 0;
   e->spans_used = 0;
+  return ICAP_OK;
+}
+
+int icap_engine_set_timing_every(icap_engine* e, int n) {
+  ICAP_REQUIRE(e, "icap_engine_set_timing_every: null engine");
+  ICAP_REQUIRE(n >= 1, "icap_engine_set_timing_every: n must be at least 1 (got %d)", n);
+  e->timing_every = n;
+  e->decode_calls = 0;
   return ICAP_OK;
 }
 

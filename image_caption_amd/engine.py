@@ -200,9 +200,11 @@ class CaptionEngine:
         """False keeps every launch on the caller's stream (no side-stream attention)."""
         _lib.call("icap_engine_set_overlap", self._handle, 1 if on else 0)
 
-    def set_timing(self, kernels):
+    def set_timing(self, kernels, every=1):
         """kernels: True (all classes), False/None (off) or an iterable of class names
-        from _lib.K_NAMES whose launches are bracketed by HIP events."""
+        from _lib.K_NAMES whose launches are bracketed by HIP events; every: bracket them in
+        every n-th decode call only."""
+        _lib.call("icap_engine_set_timing_every", self._handle, int(every))
         if kernels is True:
             mask = (1 << len(_lib.K_NAMES)) - 1
         elif not kernels:

@@ -388,6 +388,11 @@ int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
 #define ICAP_K_BACKTRACK 9
 #define ICAP_K_COUNT 10
 int icap_engine_set_timing(icap_engine* engine, unsigned class_mask);
+/* Brackets the selected classes in every n-th decode call only (n >= 1, default 1; the count
+ * restarts when the mask is set): an event pair costs the stream a few microseconds per
+ * launch, so a sample keeps a timed run close to an untimed one.  No counterpart in the
+ * reference. */
+int icap_engine_set_timing_every(icap_engine* engine, int n);
 /* By default the attention of step t+1 runs on an engine-owned side stream beside the vocab
  * projection and beam step of step t (it only depends on the LSTM of step t).  on == 0
  * keeps every launch on the caller's stream, e.g. to time kernels one by one; results are

@@ -195,6 +195,36 @@ def test_decode_schedules(monkeypatch, schedule, W):
         assert nbad == 0
 
 
+def test_kernel_timing_classes_and_sampling():
+    """Event-bracketed kernel classes: launch counts per decode, sampling every n-th decode,
+    and identical tokens with timing on or off."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    T = 5
+    p = co.make_params(3, **FUSABLE)
+    img = to_dev(co.make_images(4, 6, 5, FUSABLE["F"]))
+    cfg = CaptionConfig(B=6, W=3, L=5, F=FUSABLE["F"], D=FUSABLE["D"], E=FUSABLE["E"], H=FUSABLE["H"],
+                        U=FUSABLE["H"], V=FUSABLE["V"], T=T, start_id=3, eos_id=4)
+    eng = CaptionEngine(cfg, p, device=dev())
+    ref = np_of(eng.decode(img)[0])
+    eng.set_timing(True)
+    np.testing.assert_array_equal(np_of(eng.decode(img)[0]), ref)
+    times = eng.kernel_times()
+    assert times["lstm"][1] == T and times["vocab"][1] == T and times["beam"][1] == T
+    assert times["attention"][1] == T and times["encode"][1] == 1 and times["backtrack"][1] == 1
+    assert all(ms >= 0.0 for ms, _ in times.values())
+    eng.set_timing(["vocab"], every=3)
+    for _ in range(7):                                  # decodes 0, 3 and 6 are bracketed
+        np.testing.assert_array_equal(np_of(eng.decode(img)[0]), ref)
+    times = eng.kernel_times()
+    assert times["vocab"][1] == 3 * T and times["lstm"][1] == 0
+    eng.set_timing(False, every=1)
+    eng.decode(img)
+    assert eng.kernel_times()["vocab"][1] == 0
+    with pytest.raises(Exception):
+        eng.set_timing(True, every=0)
+    eng.close()
+
+
 def test_decode_length_penalty_and_wide_beam():
     nbad, _ = _compare_decode({}, dict(F=40, D=16, E=12, H=20, V=101), seed=2, B=4, L=9, T=8,
                               W=5, tile_mode="repeat", bias_seed=3, lpw=1.2)
