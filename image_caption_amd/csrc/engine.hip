@@ -773,10 +773,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     // (small launches, kernel tails) instead of competing with the vocab projection.
     int prio_low = 0, prio_high = 0;
     err = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    static const char* prio_env = getenv("ICAP_SIDE_PRIORITY");  // tuning knob: "default"
+    static const char* prio_env = getenv("ICAP_SIDE_PRIORITY");  // tuning knob: "default", "high"
     if (err == hipSuccess) {
       if (prio_env && prio_env[0] == 'd')
         err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+      else if (prio_env && prio_env[0] == 'h')
+        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_high);
       else
         err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_low);
     }
