@@ -326,8 +326,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // - a few microseconds on the main stream: 98.5k against 96.3k captions/s in exact-f32
   // mode and 115k against 100k in split mode at the headline shape; two or three records
   // lose it again, and the short bf16 projection loses with any (187k against 203k at beam 3).
-  // A timing bracket around the projection is such a record already.  Tuning knob
-  // ICAP_VOCAB_GATE=0|1.
+  // A timing bracket around the projection is such a record already.  Only the fused
+  // projection gets it: the plain one of small batches loses 1-2 % with it (B = 128 / 256 at
+  // beam 3: 51.9k / 72.1k against 52.9k / 72.8k; fused, B = 384 / 1024: 83.9k / 105.7k against
+  // 80.4k / 101.0k).  Tuning knob ICAP_VOCAB_GATE=0|1.
   static const char* gate_env = getenv("ICAP_VOCAB_GATE");
   const bool vocab_gate = gate_env ? gate_env[0] == '1' : c.precision != ICAP_PRECISION_BF16;
   auto attention_step = [&](hipStream_t st, const float* state) -> int {
@@ -459,8 +461,6 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           c.V, s));
       continue;
     }
-    if (t + 1 < c.T && side && vocab_gate && !((e->timing >> ICAP_K_VOCAB) & 1u))
-      ICAP_HIP(hipEventRecord(e->ev_gate, s));
     {  // K8: vocab projection
       Timed tm(e, ICAP_K_VOCAB, s);
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
