@@ -118,15 +118,19 @@ def _as_u8(finished):
 def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None, start_offset=0):
     """One batched beam-search step (reference `:360-543`).
 
-    logits [B, W, V]; state tensors [B, W].  At time 0 only beam `start_offset` is
-    scored.  `prob_fn` None means log-softmax (the reference default, fused in the
-    kernel); a custom callable is applied to the [B*W, V] logits first and its output
-    is taken as log-probabilities."""
+    logits [B, R, V]; state tensors [B, R]; config.beam_width successors per image come
+    out.  R is usually the beam width; the beam-search-optimisation trainer passes the gold
+    row in front of the search rows (R = beam_width + 1, `start_offset=1`,
+    utils/train_utils.py:275-279).  At time 0 only beam `start_offset` is scored.
+    `prob_fn` None means log-softmax (the reference default, fused in the kernel); a custom
+    callable is applied to the [B*R, V] logits first and its output is taken as
+    log-probabilities."""
     B, Wl, V = logits.shape
     if V != config.vocab_size:
         raise ValueError("logits last dim %d != config.vocab_size %d" % (V, config.vocab_size))
-    if Wl != config.beam_width:
-        raise ValueError("logits beam dim %d != config.beam_width %d" % (Wl, config.beam_width))
+    if tuple(beam_state.log_probs.shape) != (B, Wl):
+        raise ValueError("beam state of shape %s for logits with %d x %d rows"
+                         % (tuple(beam_state.log_probs.shape), B, Wl))
     time_ = int(time_)
     logits = logits.contiguous()
     is_log_prob = False
@@ -139,7 +143,8 @@ def beam_search_step_batch(time_, logits, beam_state, config, prob_fn=None, star
     scores, ids, parents, nlp, nfin, nlen = ops.beam_step(
         logits, beam_state.log_probs.contiguous(), _as_u8(beam_state.finished),
         beam_state.lengths.contiguous(), time_, config.eos_token,
-        config.length_penalty_weight, start_offset=start_offset, input_is_log_prob=is_log_prob)
+        config.length_penalty_weight, start_offset=start_offset, input_is_log_prob=is_log_prob,
+        beam_width=config.beam_width)
     next_state = BeamSearchState(log_probs=nlp, lengths=nlen, finished=nfin.view(torch.bool))
     output = BeamSearchStepOutput(scores=scores, predicted_ids=ids, beam_parent_ids=parents)
     return output, next_state

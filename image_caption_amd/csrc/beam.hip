@@ -43,11 +43,12 @@ struct BeamArgs {
   uint8_t* next_fin;
   int32_t* next_len;
   int B, W, V;
+  int R;  // rows (beams) per image in the inputs; W successors per image come out
   // workspace: per (image,row) statistics, then candidate slots
-  float2* ws_stats;  // [B*W] (max, lse)
-  float* ws_score;   // [B*W*WL_MAX]
-  float* ws_total;   // [B*W*WL_MAX]
-  int* ws_idx;       // [B*W*WL_MAX]
+  float2* ws_stats;  // [B*R] (max, lse)
+  float* ws_score;   // [B*R*WL_MAX]
+  float* ws_total;   // [B*R*WL_MAX]
+  int* ws_idx;       // [B*R*WL_MAX]
   Penalty pen;
 };
 
@@ -173,13 +174,13 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
   __shared__ float s_bt[NWV];
   __shared__ int s_bi[NWV];
 
-  const int W = p.W, V = p.V;
-  const int b = blockIdx.x / W;
-  const int w = blockIdx.x % W;
+  const int R = p.R, V = p.V;
+  const int b = blockIdx.x / R;
+  const int w = blockIdx.x % R;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const size_t rw = (size_t)b * W + w;
+  const size_t rw = (size_t)b * R + w;
 
   const bool first = p.time <= 0;
   const bool scan = first ? (w == p.start_offset) : true;
@@ -406,16 +407,17 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
   }
 }
 
-// One wavefront per image, four images per workgroup.
+// One wavefront per image, four images per workgroup.  WL >= max(R, W): the R rows'
+// candidate slots and the W winners both fit the template.
 template <int WL>
 __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= p.B) return;
-  const int W = p.W, V = p.V;
+  const int W = p.W, R = p.R, V = p.V;
   const bool first = p.time <= 0;
   const int row_lo = first ? p.start_offset : 0;
-  const int row_hi = first ? p.start_offset + 1 : W;
+  const int row_hi = first ? p.start_offset + 1 : R;
 
   // candidate slots: row w owns slots [w*(WL+2), (w+1)*(WL+2))
   constexpr int SLOTS_PER_ROW = WL + 2;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
     ct[k] = 0.f;
     ci[k] = EMPTY_IDX;
     if (w >= row_lo && w < row_hi) {
-      const size_t rw = (size_t)b * W + w;
+      const size_t rw = (size_t)b * R + w;
       const int flat0 = first ? 0 : w * V;
       if (p.finished[rw]) {
         // Finished beam: the masked log-prob is 0 at eos and f32.min elsewhere whatever
@@ -471,8 +473,8 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
     if (lane == r) { my_s = bs; my_t = bt; my_i = bi; }
   }
 
-  // Lanes 0..W-1 finish one winner each.  The next-state buffers may be the state
-  // inputs themselves: one wave owns the image and every load below precedes every
+  // Lanes 0..W-1 finish one winner each.  With R == W the next-state buffers may be the
+  // state inputs themselves: one wave owns the image and every load below precedes every
   // store in program order, so the in-place update is safe.
   const bool act = lane < W;
   const size_t o = (size_t)b * W + (act ? lane : 0);
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
   float nlp = my_t;
   if (first && p.start_offset != 0) {
     // reference quirk: at time 0 the log-prob is gathered from beam 0 at the chosen word
-    const size_t r0 = (size_t)b * W;
+    const size_t r0 = (size_t)b * R;
     float pr;
     if (p.finished[r0]) {
       pr = (word == p.eos) ? 0.f : kF32Min;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
     }
     nlp = p.log_probs[r0] + pr;
   }
-  const size_t rp = (size_t)b * W + parent;
+  const size_t rp = (size_t)b * R + parent;
   const int pfin = p.finished[rp] ? 1 : 0;
   const int plen = p.lengths[rp];
   const int nfin = (pfin || word == p.eos) ? 1 : 0;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const int32_t* __restric
 
 template <int NT, int ITEMS, int WL>
 int launch_row(const BeamArgs& a, bool vec, hipStream_t s) {
-  const dim3 grid(a.B * a.W), block(NT);
+  const dim3 grid(a.B * a.R), block(NT);
   if (vec)
     hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, WL, true>), grid, block, 0, s, a);
   else
@@ -802,12 +804,16 @@ size_t beam_step_workspace_bytes(int B, int W) {
   return rows * sizeof(float2) + 3 * rows * WL_MAX * sizeof(float);
 }
 
-int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
-                  const int32_t* lengths, int time, int start_offset, int eos_token,
-                  double length_penalty_weight, int input_is_log_prob, float* scores,
-                  int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
-                  uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
-                  void* workspace, size_t workspace_bytes, hipStream_t s) {
+// R input rows (beams) per image, W successors out: state inputs [B,R], outputs [B,W].  The
+// reference's step takes any number of rows (beam_search.py:375-455 reshapes by vocab size
+// only); its beam-search-optimisation trainer passes gold + search rows, R = W + 1
+// (utils/train_utils.py:275-279).
+int beam_step_rows_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                       const int32_t* lengths, int time, int start_offset, int eos_token,
+                       double length_penalty_weight, int input_is_log_prob, float* scores,
+                       int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                       uint8_t* next_finished, int32_t* next_lengths, int B, int R, int W, int V,
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
   ICAP_REQUIRE(logits && log_probs && finished && lengths, "beam_step_f32: null input");
   ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
                    next_lengths,
@@ -815,23 +821,25 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   ICAP_REQUIRE(B > 0 && V > 0, "beam_step_f32: bad shape");
   ICAP_REQUIRE(W >= 1 && W <= ICAP_MAX_BEAM_WIDTH, "beam_step_f32: beam width %d outside [1,%d]",
                W, ICAP_MAX_BEAM_WIDTH);
+  ICAP_REQUIRE(R >= 1 && R <= ICAP_MAX_BEAM_WIDTH, "beam_step_f32: %d rows per image outside [1,%d]",
+               R, ICAP_MAX_BEAM_WIDTH);
   ICAP_REQUIRE(W <= V, "beam_step_f32: beam width %d exceeds vocab size %d", W, V);
-  ICAP_REQUIRE(start_offset >= 0 && start_offset < W,
-               "beam_step_f32: start_offset %d outside [0,%d)", start_offset, W);
-  ICAP_REQUIRE((long long)W * V < (1LL << 31), "beam_step_f32: W*V overflows int32");
+  ICAP_REQUIRE(start_offset >= 0 && start_offset < R,
+               "beam_step_f32: start_offset %d outside [0,%d)", start_offset, R);
+  ICAP_REQUIRE((long long)R * V < (1LL << 31), "beam_step_f32: rows*V overflows int32");
   ICAP_REQUIRE(workspace && aligned16(workspace),
                "beam_step_f32: workspace must be a 16-byte aligned device pointer");
-  ICAP_REQUIRE(workspace_bytes >= beam_step_workspace_bytes(B, W),
+  ICAP_REQUIRE(workspace_bytes >= beam_step_workspace_bytes(B, R),
                "beam_step_f32: workspace of %zu bytes is smaller than the %zu needed",
-               workspace_bytes, beam_step_workspace_bytes(B, W));
+               workspace_bytes, beam_step_workspace_bytes(B, R));
   BeamArgs a;
   a.logits = logits; a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
   a.time = time; a.start_offset = start_offset; a.eos = eos_token;
   a.input_is_log_prob = input_is_log_prob;
   a.scores = scores; a.ids = predicted_ids; a.parents = parent_ids;
   a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
-  a.B = B; a.W = W; a.V = V;
-  const size_t rows = (size_t)B * W;
+  a.B = B; a.W = W; a.V = V; a.R = R;
+  const size_t rows = (size_t)B * R;
   char* wsp = static_cast<char*>(workspace);
   a.ws_stats = reinterpret_cast<float2*>(wsp);
   a.ws_score = reinterpret_cast<float*>(wsp + rows * sizeof(float2));
@@ -839,11 +847,24 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   a.ws_idx = reinterpret_cast<int*>(a.ws_total + rows * WL_MAX);
   a.pen = make_penalty(length_penalty_weight);
   const bool vec = (V % 4 == 0) && aligned16(logits);
-  if (W <= 1) return dispatch_beam<1>(a, vec, s);
-  if (W <= 3) return dispatch_beam<3>(a, vec, s);
-  if (W <= 5) return dispatch_beam<5>(a, vec, s);
-  if (W <= 10) return dispatch_beam<10>(a, vec, s);
+  const int wl = W > R ? W : R;  // candidate slots per row: the winners and the rows both fit
+  if (wl <= 1) return dispatch_beam<1>(a, vec, s);
+  if (wl <= 3) return dispatch_beam<3>(a, vec, s);
+  if (wl <= 5) return dispatch_beam<5>(a, vec, s);
+  if (wl <= 10) return dispatch_beam<10>(a, vec, s);
   return dispatch_beam<16>(a, vec, s);
+}
+
+int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                  const int32_t* lengths, int time, int start_offset, int eos_token,
+                  double length_penalty_weight, int input_is_log_prob, float* scores,
+                  int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                  uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
+                  void* workspace, size_t workspace_bytes, hipStream_t s) {
+  return beam_step_rows_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
+                            length_penalty_weight, input_is_log_prob, scores, predicted_ids,
+                            parent_ids, next_log_probs, next_finished, next_lengths, B, W, W, V,
+                            workspace, workspace_bytes, s);
 }
 
 // Records one workgroup can hold in registers (8 per thread); more take the unfused kernels.

@@ -89,6 +89,9 @@ int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream
 int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
                   double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
                   int, void*, size_t, hipStream_t);
+int beam_step_rows_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
+                       double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
+                       int, int, void*, size_t, hipStream_t);
 size_t beam_step_workspace_bytes(int B, int W);
 int beam_scores_f32(const float*, const float*, const uint8_t*, const int32_t*, int, double, int,
                     float*, float*, int, int, int, hipStream_t);
@@ -493,7 +496,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 108; }
+int icap_version(void) { return 109; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -620,6 +623,18 @@ int icap_beam_step_f32(const float* logits, const float* log_probs, const uint8_
                        length_penalty_weight, input_is_log_prob, scores, predicted_ids, parent_ids,
                        next_log_probs, next_finished, next_lengths, B, W, V, workspace,
                        workspace_bytes, (hipStream_t)stream);
+}
+
+int icap_beam_step_rows_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                            const int32_t* lengths, int time, int start_offset, int eos_token,
+                            double length_penalty_weight, int input_is_log_prob, float* scores,
+                            int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                            uint8_t* next_finished, int32_t* next_lengths, int B, int R, int W,
+                            int V, void* workspace, size_t workspace_bytes, icap_stream_t stream) {
+  return beam_step_rows_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
+                            length_penalty_weight, input_is_log_prob, scores, predicted_ids,
+                            parent_ids, next_log_probs, next_finished, next_lengths, B, R, W, V,
+                            workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 size_t icap_beam_step_workspace_bytes(int B, int W) { return beam_step_workspace_bytes(B, W); }

@@ -260,9 +260,11 @@ def _beam_workspace(B, W, device):
 
 
 def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_penalty_weight,
-              start_offset=0, input_is_log_prob=False):
-    """Returns (scores, ids, parents, next_log_probs, next_finished(u8), next_lengths)."""
-    B, W, V = logits.shape
+              start_offset=0, input_is_log_prob=False, beam_width=None):
+    """logits [B,R,V], state [B,R] -> (scores, ids, parents, next_log_probs, next_finished(u8),
+    next_lengths), each [B,W]; W = beam_width (default: the R rows of the input)."""
+    B, R, V = logits.shape
+    W = R if beam_width is None else int(beam_width)
     dev = logits.device
     scores = torch.empty(B, W, dtype=f32, device=dev)
     ids = torch.empty(B, W, dtype=i32, device=dev)
@@ -270,13 +272,13 @@ def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_pena
     nlp = torch.empty(B, W, dtype=f32, device=dev)
     nfin = torch.empty(B, W, dtype=u8, device=dev)
     nlen = torch.empty(B, W, dtype=i32, device=dev)
-    ws = _beam_workspace(B, W, dev)
-    _lib.call("icap_beam_step_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
-              _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(time),
-              int(start_offset), int(eos_token), float(length_penalty_weight),
-              1 if input_is_log_prob else 0, scores.data_ptr(), ids.data_ptr(),
-              parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(), B, W, V,
-              ws.data_ptr(), ws.numel(), current_stream())
+    ws = _beam_workspace(B, R, dev)
+    _lib.call("icap_beam_step_rows_f32", _chk(logits, f32, "logits"),
+              _chk(log_probs, f32, "log_probs"), _chk(finished, u8, "finished"),
+              _chk(lengths, i32, "lengths"), int(time), int(start_offset), int(eos_token),
+              float(length_penalty_weight), 1 if input_is_log_prob else 0, scores.data_ptr(),
+              ids.data_ptr(), parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(), nlen.data_ptr(),
+              B, R, W, V, ws.data_ptr(), ws.numel(), current_stream())
     return scores, ids, parents, nlp, nfin, nlen
 
 

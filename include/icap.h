@@ -216,6 +216,21 @@ int icap_beam_step_f32(const float* logits, const float* log_probs,
                        float* next_log_probs, uint8_t* next_finished,
                        int32_t* next_lengths, int B, int W, int V,
                        void* workspace, size_t workspace_bytes, icap_stream_t stream);
+/* The same step with R input rows (beams) per image and W successors out: logits[B,R,V],
+ * log_probs / finished / lengths [B,R]; outputs [B,W]; parent_ids in [0,R); start_offset in
+ * [0,R); workspace of icap_beam_step_workspace_bytes(B, R) bytes; R, W <=
+ * ICAP_MAX_BEAM_WIDTH.  beam_search_step_batch takes any number of rows
+ * (beam_search.py:375-455 reshapes by vocab size only); the beam-search-optimisation trainer
+ * calls it with the gold row in front of the search rows, R = W + 1 and start_offset = 1
+ * (utils/train_utils.py:275-279). */
+int icap_beam_step_rows_f32(const float* logits, const float* log_probs,
+                            const uint8_t* finished, const int32_t* lengths,
+                            int time, int start_offset, int eos_token,
+                            double length_penalty_weight, int input_is_log_prob,
+                            float* scores, int32_t* predicted_ids, int32_t* parent_ids,
+                            float* next_log_probs, uint8_t* next_finished,
+                            int32_t* next_lengths, int B, int R, int W, int V,
+                            void* workspace, size_t workspace_bytes, icap_stream_t stream);
 
 /* The beam-search step in two halves, for a caller-supplied successor choice
  * (BeamSearchConfig.choose_successors_fn other than choose_top_k).

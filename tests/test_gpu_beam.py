@@ -149,6 +149,41 @@ def test_beam_step_start_offset_and_custom_prob_fn(bs):
     _check_step(bs, logits, _random_state(rng, B, W, 3), 3, W, V, 2, 1.0, prob_fn=True)
 
 
+@pytest.mark.parametrize("B,R,W,V,t", [
+    (3, 4, 3, 23, 0), (3, 4, 3, 23, 2), (2, 6, 5, 1000, 3), (4, 2, 1, 40, 1), (2, 1, 3, 50, 2),
+    (2, 11, 10, 300, 4), (3, 4, 3, 10000, 5), (2, 16, 3, 64, 2), (2, 3, 16, 64, 1)])
+def test_beam_step_rows_differ_from_beam_width(bs, B, R, W, V, t):
+    """Gold + search rows of the beam-search-optimisation trainer (utils/train_utils.py:
+    275-279: R = W + 1 rows in, W successors out, start_offset = 1 at time 0) and other row
+    counts: parents index the R input rows."""
+    rng = np.random.default_rng(B * 100 + R * 10 + W + V + t)
+    logits = rng.standard_normal((B, R, V)).astype(np.float32) * 2
+    state = _random_state(rng, B, R, t)
+    eos = int(rng.integers(0, V))
+    off = 1 if R > 1 else 0
+    out_o, _, out_g, nst_g = _check_step(bs, logits, state, t, W, V, eos, 1.2, start_offset=off)
+    assert tuple(out_g.scores.shape) == (B, W) and tuple(nst_g.lengths.shape) == (B, W)
+    if t > 0:
+        assert int(np_of(out_g.beam_parent_ids).max()) < R
+    # the trainer's gold step: one row, a mask added to the log-softmax (GoldProbFn, :70-78)
+    mask = np.full((V,), np.float32(-1e9))
+    mask[int(rng.integers(0, V))] = 0.0
+    gold_o = lambda x: co.log_softmax(x) + mask
+    gold_g = lambda x: torch.log_softmax(x, dim=-1) + to_dev(mask)
+    st1 = _random_state(rng, B, 1, t)
+    cfg_o = co.BeamSearchConfig(1, V, eos, 1.2, co.choose_top_k)
+    cfg_g = bs.BeamSearchConfig(1, V, eos, 1.2, bs.choose_top_k)
+    o_o, s_o = co.beam_search_step_batch(t, logits[:, :1], st1, cfg_o, prob_fn=gold_o)
+    o_g, s_g = bs.beam_search_step_batch(
+        t, to_dev(logits[:, :1].copy()),
+        bs.BeamSearchState(to_dev(st1.log_probs), to_dev(st1.finished), to_dev(st1.lengths)),
+        cfg_g, prob_fn=gold_g)
+    np.testing.assert_array_equal(np_of(o_g.predicted_ids), o_o.predicted_ids)
+    with np.errstate(over="ignore"):
+        assert_close(np.maximum(np_of(s_g.log_probs), -1e30), np.maximum(s_o.log_probs, -1e30),
+                     what="gold log_probs")
+
+
 def test_beam_step_monotone_logits_worst_case_insertion(bs):
     """Increasing logits make every element a new maximum (the slow insertion path)."""
     B, W, V = 2, 3, 3000
