@@ -225,6 +225,45 @@ def test_kernel_timing_classes_and_sampling():
     eng.close()
 
 
+def test_decode_can_be_captured_into_a_graph():
+    """icap_decode only enqueues (caller's stream + the engine's side stream joined by
+    events, no synchronisation, no allocation), so a caller may capture it into a HIP graph;
+    replays give the tokens of a direct call, also for new input in the same buffer."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = co.make_params(5, **FUSABLE)
+    cfg = CaptionConfig(B=6, W=3, L=5, F=FUSABLE["F"], D=FUSABLE["D"], E=FUSABLE["E"], H=FUSABLE["H"],
+                        U=FUSABLE["H"], V=FUSABLE["V"], T=6, start_id=3, eos_id=4)
+    eng = CaptionEngine(cfg, p, device=dev())
+    prefer_fused(eng)
+    img_a = to_dev(co.make_images(6, 6, 5, FUSABLE["F"]))
+    img_b = to_dev(co.make_images(7, 6, 5, FUSABLE["F"]))
+    ref_a = np_of(eng.decode(img_a)[0])
+    ref_b = np_of(eng.decode(img_b)[0])
+    assert (ref_a != ref_b).any()
+    buf = img_a.clone()
+    out = torch.empty(6, 6, dtype=torch.int32, device=dev())
+    sc = torch.empty(6, dtype=torch.float32, device=dev())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up off the default stream
+        eng.decode(buf, out, sc)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.decode(buf, out, sc)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(np_of(out), ref_a)
+    buf.copy_(img_b)
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(np_of(out), ref_b)
+    del g
+    eng.close()
+
+
 def test_decode_length_penalty_and_wide_beam():
     nbad, _ = _compare_decode({}, dict(F=40, D=16, E=12, H=20, V=101), seed=2, B=4, L=9, T=8,
                               W=5, tile_mode="repeat", bias_seed=3, lpw=1.2)
