@@ -2,6 +2,7 @@
 parity-unpinned stage with independent torch-CPU primitives.  The reference has no
 test for these stages, so this is a cross-check, not a reference-derived pin."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -188,3 +189,109 @@ def test_baseline_searcher_oracle_forces_eos_at_the_target_length():
     tok5 = co.baseline_sequence_beam_search(p, feats, seqs, 2, DIMS["V"], 5, 3, 4, 0)
     assert tok5.shape == (1, 5) and tok5[0, 0] == 3 and (tok5[0, 1:] != 3).all()
     assert co.sequence_length_fn(seqs, 0).tolist() == [5]
+
+
+# ---- transformer path: the oracle's restatement against independent torch-CPU primitives ----
+
+def test_layer_norm_matches_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, 7, 48)).astype(np.float32) * 3 + 1
+    g = (1 + 0.1 * rng.standard_normal(48)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(48)).astype(np.float32)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (48,), torch.from_numpy(g),
+                                         torch.from_numpy(b), eps=1e-6).numpy()
+    np.testing.assert_allclose(co.layer_norm(x, g, b), ref, rtol=2e-5, atol=2e-6)
+
+
+def test_position_embedding_matches_the_published_formula():
+    """sin / cos of pos / 10000^(i / (n - 1)), n = hidden / 2 timescales ("Attention is all
+    you need" 3.5 as tensor2tensor lays it out: all sines, then all cosines)."""
+    length, hidden = 23, 64
+    n = hidden // 2
+    pos = torch.arange(length, dtype=torch.float64)[:, None]
+    inv = torch.pow(torch.tensor(1.0e4, dtype=torch.float64),
+                    -torch.arange(n, dtype=torch.float64) / (n - 1))[None, :]
+    ref = torch.cat([torch.sin(pos * inv), torch.cos(pos * inv)], dim=1).numpy()
+    got = co.relative_position_embedding(length, hidden)
+    assert got.shape == (length, hidden) and got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, rtol=0, atol=5e-6)
+
+
+def test_decoder_self_attention_bias_is_causal():
+    b = co.decoder_self_attention_bias(5)
+    assert b.shape == (1, 1, 5, 5)
+    assert (b[0, 0][np.tril_indices(5)] == 0).all()
+    assert (b[0, 0][np.triu_indices(5, 1)] == np.float32(-1e9)).all()
+
+
+def _mha_params(rng, d_q, d_kv, heads, key_dim, prefix="m_"):
+    HD = heads * key_dim
+    p = {}
+    for name, shape in (("q_kernel", (d_q, HD)), ("k_kernel", (d_kv, HD)), ("v_kernel", (d_kv, HD)),
+                        ("o_kernel", (HD, d_q))):
+        p[prefix + name] = (rng.standard_normal(shape) / np.sqrt(shape[0])).astype(np.float32)
+    for name, n in (("q_bias", HD), ("k_bias", HD), ("v_bias", HD), ("o_bias", d_q)):
+        p[prefix + name] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_multi_head_attention_matches_torch_sdpa(causal):
+    """With a 0/1 mask (or none) the oracle's attention is ordinary scaled dot-product attention
+    per head."""
+    rng = np.random.default_rng(3)
+    B, T, S, d_q, d_kv, heads, kd = 2, 5, 5 if causal else 7, 24, 24 if causal else 16, 3, 8
+    p = _mha_params(rng, d_q, d_kv, heads, kd)
+    q_in = rng.standard_normal((B, T, d_q)).astype(np.float32)
+    kv_in = q_in if causal else rng.standard_normal((B, S, d_kv)).astype(np.float32)
+    mask = np.tril(np.ones((T, S), np.float32)).reshape(1, 1, T, S) if causal else None
+    got = co.multi_head_attention(q_in, kv_in, p, "m_", heads, kd, attention_mask=mask)
+    tq, tkv = torch.from_numpy(q_in), torch.from_numpy(kv_in)
+    proj = lambda x, k: (x @ torch.from_numpy(p["m_" + k + "_kernel"]) + torch.from_numpy(p["m_" + k + "_bias"]))
+    split = lambda x: x.reshape(x.shape[0], x.shape[1], heads, kd).permute(0, 2, 1, 3)
+    o = torch.nn.functional.scaled_dot_product_attention(
+        split(proj(tq, "q")), split(proj(tkv, "k")), split(proj(tkv, "v")), is_causal=causal)
+    o = o.permute(0, 2, 1, 3).reshape(B, T, heads * kd)
+    ref = (o @ torch.from_numpy(p["m_o_kernel"]) + torch.from_numpy(p["m_o_bias"])).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_bias_passed_as_mask_gives_a_uniform_causal_mean():
+    """The reference hands the additive causal bias to `attention_mask` (transform_decoder.py:
+    139 -> attention.py:471-473): visible positions get -1e9 added in fp32, which absorbs the
+    scores, hidden ones about -1e18 - the weights become uniform over the visible prefix."""
+    rng = np.random.default_rng(4)
+    B, T, d, heads, kd = 2, 6, 16, 4, 4
+    p = _mha_params(rng, d, d, heads, kd)
+    x = rng.standard_normal((B, T, d)).astype(np.float32)
+    got = co.multi_head_attention(x, x, p, "m_", heads, kd,
+                                  attention_mask=co.decoder_self_attention_bias(T))
+    v = x @ p["m_v_kernel"] + p["m_v_bias"]                       # [B,T,HD]
+    mean = np.cumsum(v, axis=1) / np.arange(1, T + 1, dtype=np.float32)[None, :, None]
+    ref = mean @ p["m_o_kernel"] + p["m_o_bias"]
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_transformer_step_equals_full_prefix_recomputation():
+    """Growing the prefix one token at a time gives, at every position, the output the stack
+    computes for that position of the full sequence (what an incremental engine relies on)."""
+    dims = dict(F=12, D=8, V=30, hidden=16, n_layers=2, heads=16, key_dim=4, filter_size=32)
+    p = co.perturb_transformer_params(co.make_transformer_params(1, **dims), 2)
+    rng = np.random.default_rng(5)
+    N, L, T = 3, 4, 5
+    feats = rng.standard_normal((N, L, dims["D"])).astype(np.float32)
+    ids = rng.integers(0, dims["V"], size=(N, T)).astype(np.int32)
+    full = None
+    hidden = [np.zeros((N, 1), np.int32)]
+    for t in range(T):
+        logits, hidden, _, last = co.transform_decoder_step(p, ids[:, t], feats, hidden,
+                                                            dims["n_layers"], dims["heads"], dims["key_dim"])
+        x = p["t_embedding"][hidden[0]]
+        x = x + co.relative_position_embedding(hidden[0].shape[1], dims["hidden"])[None]
+        full = co.transformer_decoder_stack(p, x, feats, dims["n_layers"], dims["heads"], dims["key_dim"])
+        np.testing.assert_allclose(last, full[:, -1], rtol=1e-5, atol=1e-6)
+    assert hidden[0].shape == (N, T + 1) and (hidden[0][:, 0] == 0).all()
+    # earlier positions are unchanged by later tokens (causality)
+    x_short = p["t_embedding"][hidden[0][:, :3]] + co.relative_position_embedding(3, dims["hidden"])[None]
+    short = co.transformer_decoder_stack(p, x_short, feats, dims["n_layers"], dims["heads"], dims["key_dim"])
+    np.testing.assert_allclose(short, full[:, :3], rtol=1e-5, atol=1e-6)
