@@ -36,6 +36,7 @@ struct AttArgs {
   const float* q_state;  // [N,H]
   const float* q_w;      // [H,U]
   const float* q_b;      // [U] or null
+  int high_prio = 0;     // the kernel's waves raise their issue priority
 };
 
 #if defined(__HIPCC__)
