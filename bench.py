@@ -304,9 +304,9 @@ def main():
     sync()
     # ---- timed region: exactly `steps` steps.  The launches of the dominant kernel (the
     # vocab projection) are bracketed by HIP events on the decode stream inside it - in every
-    # fourth decode, an event pair costs the stream a few microseconds per launch; they feed
+    # fifth decode, an event pair costs the stream a few microseconds per launch; they feed
     # the roofline object. ----
-    eng.set_timing(["vocab"], every=4 if args.steps >= 8 else 1)   # a sample of the decodes
+    eng.set_timing(["vocab"], every=5 if args.steps >= 10 else 1)   # a sample of the decodes
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()

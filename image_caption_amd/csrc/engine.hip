@@ -325,16 +325,20 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // The side stream's attention has to be resident before the vocab projection's workgroups
   // arrive: launched after them it waits for the projection's first round of tiles and ends
   // up on the critical path.  Its launch (behind the query kernel) and the projection's
-  // (behind fc1) are a close race, so one idle event record goes in front of the projection
-  // - a few microseconds on the main stream: 98.5k against 96.3k captions/s in exact-f32
-  // mode and 115k against 100k in split mode at the headline shape; two or three records
-  // lose it again, and the short bf16 projection loses with any (187k against 203k at beam 3).
-  // A timing bracket around the projection is such a record already.  Only the fused
-  // projection gets it: the plain one of small batches loses 1-2 % with it (B = 128 / 256 at
-  // beam 3: 51.9k / 72.1k against 52.9k / 72.8k; fused, B = 384 / 1024: 83.9k / 105.7k against
-  // 80.4k / 101.0k).  Tuning knob ICAP_VOCAB_GATE=0|1.
+  // (behind fc1) are a close race; one idle event record in front of the fused projection
+  // (a few microseconds on the main stream) settles it where it matters: split mode (113k
+  // against 104k captions/s at the headline shape) and long exact-f32 projections (B = 1024,
+  // beam 3: 106.7k against 100.8k; B = 512, beam 5: 57.0k against 56.7k).  At the headline
+  // shape itself the exact-f32 path is better without it (99.8k against 98.8k; B = 384: 84.9k
+  // against 84.1k), the short bf16 projection loses with it (187k against 203k at beam 3),
+  // and so does the plain projection of small batches (1-2 %).  Two or three records lose
+  // the gain again; a timing bracket around the projection is such a record already.
+  // Tuning knob ICAP_VOCAB_GATE=0|1.
   static const char* gate_env = getenv("ICAP_VOCAB_GATE");
-  const bool vocab_gate = gate_env ? gate_env[0] == '1' : c.precision != ICAP_PRECISION_BF16;
+  const long gate_tiles = (long)ceil_div(N, 128) * ceil_div(c.V, 128);
+  const bool vocab_gate = gate_env ? gate_env[0] == '1'
+                                   : (c.precision == ICAP_PRECISION_F32_SPLIT ||
+                                      (c.precision == ICAP_PRECISION_FP32 && gate_tiles >= 1400));
   auto attention_step = [&](hipStream_t st, const float* state) -> int {
     if (st != s && side_fq) {  // K4+K5 in one launch
       Timed tm(e, ICAP_K_ATTENTION, st);
