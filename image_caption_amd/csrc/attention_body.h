@@ -247,6 +247,9 @@ inline size_t attention_fq_lds_floats(int nt, int R, int ip, int L, int U, int D
   return sw + ATT_MAX_ROWS + part + rows * U;
 }
 
+#ifndef ICAP_FQ_LB512
+#define ICAP_FQ_LB512 4
+#endif
 #ifndef ICAP_FQ_QU
 #define ICAP_FQ_QU 4
 #endif
@@ -256,7 +259,7 @@ inline size_t attention_fq_lds_floats(int nt, int R, int ip, int L, int U, int D
 #if defined(__HIPCC__)
 template <int NT, int RB, int IP>
 __device__ __forceinline__ void attention_fq_body(const AttArgs& p, char* smem, int first, int stride) {
-  constexpr int WAVES = NT / 64, ROWS = RB * IP, UCH = 2, LB = NT >= 512 ? 4 : ICAP_FQ_LB;
+  constexpr int WAVES = NT / 64, ROWS = RB * IP, UCH = 2, LB = NT >= 512 ? ICAP_FQ_LB512 : ICAP_FQ_LB;
   float* s_w = reinterpret_cast<float*>(smem);
   const int sw_elems = ((p.R * p.L + 3) / 4) * 4;
   float* s_beta = s_w + sw_elems;

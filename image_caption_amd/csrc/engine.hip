@@ -816,8 +816,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                                 : (c.precision == ICAP_PRECISION_BF16 ? 0 : prop.multiProcessorCount);
   }
   {
-    // opt-in (ICAP_MERGED=1, read when the engine is created): measured slower than the side
-    // stream at the headline shape (the attention workgroups take a projection slot each)
+    // opt-in (ICAP_MERGED=1, read when the engine is created): measured 1 % slower than the
+    // side stream at the headline shape (the attention workgroups take a projection slot each)
     const char* merged_env = getenv("ICAP_MERGED");
     e->merged = merged_env && merged_env[0] == '1' && c.precision == ICAP_PRECISION_FP32 &&
                 e->topk_able != 0 &&

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(512, 4)  // (min 4 waves per SIMD: two workgroups p
     void dense_topk_attention_kernel(DenseArgs p, AttArgs a, int att_blocks) {
   __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
   if ((int)blockIdx.x < att_blocks) {
+    __builtin_amdgcn_s_setprio(3);  // (get out of the tiles' way sooner)
     attention_fq_body<512, RB, (RB <= 3 ? 2 : 1)>(a, reinterpret_cast<char*>(&lds), blockIdx.x, att_blocks);
     return;
   }
