@@ -264,6 +264,44 @@ def test_decode_can_be_captured_into_a_graph():
     eng.close()
 
 
+@pytest.mark.parametrize("B,L,T,W,V", [
+    (1, 1, 1, 1, 8),        # one image, one location, one step, greedy
+    (1, 3, 2, 3, 12),       # one image
+    (2, 1, 4, 2, 8),        # a single feature location: attention weights are all 1
+    (3, 4, 1, 3, 40),       # a single decode step (only the time-0 rule applies)
+    (2, 3, 5, 5, 5),        # beam width == vocab size
+    (2, 2, 3, 16, 64),      # the widest beam the library takes
+    (5, 7, 30, 3, 200)])    # longer than any caption: finished beams carried for many steps
+def test_decode_edge_sizes(B, L, T, W, V):
+    dims = dict(F=16, D=8, E=8, H=32, V=V)
+    for tile_mode in ("reference", "repeat"):
+        nbad, explained = _compare_decode({}, dims, seed=B + L + T + W, B=B, L=L, T=T, W=W,
+                                          tile_mode=tile_mode, bias_seed=2)
+        # (a long decode may hit a tie of the oracle's own scores: margin of a few ulps at most)
+        assert nbad == 0 or (T >= 30 and nbad <= 1 and all(m < 1e-6 for _, _, m in explained)), explained
+
+
+def test_engine_rejects_bad_shapes_and_arguments():
+    from image_caption_amd import _lib
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    dims = dict(F=16, D=8, E=8, H=32, V=20)
+    p = co.make_params(0, **dims)
+    base = dict(B=2, W=2, L=3, F=16, D=8, E=8, H=32, U=32, V=20, T=4, start_id=3, eos_id=4)
+    for bad in (dict(W=17), dict(W=21), dict(start_id=20), dict(B=0), dict(T=0), dict(U=30)):
+        with pytest.raises((_lib.IcapError, ValueError)):
+            CaptionEngine(CaptionConfig(**dict(base, **bad)), p, device=dev())
+    eng = CaptionEngine(CaptionConfig(**base), p, device=dev())
+    with pytest.raises(ValueError):
+        eng.decode(to_dev(co.make_images(0, 3, 3, 16)))            # wrong batch
+    with pytest.raises((TypeError, ValueError)):
+        eng.decode(to_dev(co.make_images(0, 2, 3, 16)).double())   # wrong dtype
+    with pytest.raises((TypeError, ValueError)):
+        eng.decode(torch.from_numpy(co.make_images(0, 2, 3, 16)))  # host tensor
+    tok, _ = eng.decode(to_dev(co.make_images(0, 2, 3, 16)))       # still usable afterwards
+    assert tuple(tok.shape) == (2, 4)
+    eng.close()
+
+
 def test_decode_length_penalty_and_wide_beam():
     nbad, _ = _compare_decode({}, dict(F=40, D=16, E=12, H=20, V=101), seed=2, B=4, L=9, T=8,
                               W=5, tile_mode="repeat", bias_seed=3, lpw=1.2)
