@@ -142,6 +142,12 @@ def test_tdecode_small_as_written(tile_mode, W):
     assert _compare(SMALL, seed=1, B=4, L=5, T=6, W=W, tile_mode=tile_mode) == 0
 
 
+@pytest.mark.parametrize("B,L,T,W", [(1, 1, 1, 1), (1, 2, 3, 3), (2, 1, 2, 2), (3, 4, 1, 3), (2, 3, 12, 3)])
+def test_tdecode_edge_sizes(B, L, T, W):
+    """One image / one location / one step / greedy, and a prefix longer than the usual caption."""
+    assert _compare(SMALL, seed=B + L + T, B=B, L=L, T=T, W=W, tile_mode="repeat") == 0
+
+
 def test_tdecode_small_conventional_variant():
     dims = dict(SMALL, heads=4, key_dim=8)
     assert _compare(dims, seed=2, B=3, L=6, T=7, W=3, tile_mode="repeat", mask_mode="causal",
