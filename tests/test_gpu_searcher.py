@@ -108,6 +108,28 @@ def test_search_baseline_small(cell, max_length, fused):
         assert (tok_o[:, 1:] == 4).any()
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_search_baseline_ragged_target_lengths(fused):
+    """Target lengths from 1 (start token only) to the full width, one image per length
+    class; whatever the forced eos / pad masks make of them, the engine follows the oracle."""
+    dims = dict(F=24, D=8, E=8, H=32, V=40)
+    p = _params(4, dims, "lstm", bias_seed=5)
+    rng = np.random.default_rng(6)
+    B, L, W, T = 6, 4, 3, 8
+    feats = np.abs(rng.standard_normal((B, L, dims["D"]))).astype(np.float32)
+    lengths = [1, 2, T, T - 1, 3, 1]
+    seqs = np.zeros((B, T), np.int32)
+    for b, n in enumerate(lengths):
+        seqs[b, 0] = 3
+        if n > 1:
+            seqs[b, 1:n - 1] = rng.integers(5, dims["V"], size=max(n - 2, 0))
+            seqs[b, n - 1] = 4
+    tok_o = co.baseline_sequence_beam_search(p, feats, seqs, W, dims["V"], 0, 3, 4, 0)
+    tok_g, _ = _engine_search(p, feats, seqs, W, 0, dims, "lstm", fused)
+    np.testing.assert_array_equal(tok_g, tok_o[:, 1:])
+    assert tok_o[2, T - 1] == 4                                         # eos at the target length
+
+
 @pytest.mark.parametrize("max_length,precision", [(12, "fp32"), (0, "fp32"), (0, "fp32_split")])
 def test_search_baseline_production_dims(max_length, precision):
     dims = dict(F=64, D=256, E=256, H=512, V=10000)
