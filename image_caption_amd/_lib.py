@@ -97,6 +97,7 @@ SIGNATURES = {
     "icap_beam_step_rows_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                                  _I, _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),
+    "icap_sample_categorical_f32": ([_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
     "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
     "icap_packed_weight_bytes": ([_I, _I], C.c_size_t),
     "icap_pack_weight_bf16": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),

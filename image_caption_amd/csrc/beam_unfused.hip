@@ -208,6 +208,99 @@ __global__ __launch_bounds__(NT) void expand_rows_i32_kernel(const int32_t* __re
   dst[n] = src[tile_mode == ICAP_TILE_REPEAT ? n / W : n % B];
 }
 
+// One workgroup per row: a sample from softmax(logits + token masks) by inversion of the
+// cumulative distribution at the caller's uniform number u[row] in [0,1), then the reference's
+// forcing by position (eos where step + 1 == length, pad where step >= length).
+//   pass 1  row maximum and the exp-sums of the NT contiguous column chunks (one per thread);
+//   scan    exclusive prefix of the chunk sums (wave scans + one LDS round);
+//   pass 2  the thread whose chunk holds the target mass u * total walks it.
+// Masked columns carry f32.min: their exp is exactly 0, they are never drawn.
+struct SampleArgs {
+  const float* logits;   // [N,V]
+  const float* u;        // [N]
+  const int32_t* row_len;  // [N] or null
+  int32_t* out;          // [N]
+  int V, step, start, eos, pad;
+};
+
+__global__ __launch_bounds__(NT) void sample_categorical_kernel(SampleArgs p) {
+  __shared__ float s_red[NT / 64];
+  __shared__ float s_pre[NT / 64];
+  __shared__ int s_pick;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = p.logits + (size_t)row * p.V;
+  const int chunk = (p.V + NT - 1) / NT;
+  const int c_lo = min(tid * chunk, p.V), c_hi = min(c_lo + chunk, p.V);
+  auto masked = [&](int c) -> float {
+    float v = x[c];
+    if (c == p.start) v += kF32Min;
+    if (c == p.eos) v += kF32Min;
+    if (c == p.pad) v += kF32Min;
+    return v;
+  };
+  float m = -INFINITY;
+  for (int c = c_lo; c < c_hi; ++c) m = fmaxf(m, masked(c));
+  m = wave_max(m);
+  if (lane == 0) s_red[wave] = m;
+  if (tid == 0) s_pick = -1;
+  __syncthreads();
+  m = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, s_red[w]);
+  __syncthreads();
+  float mine = 0.f;
+  for (int c = c_lo; c < c_hi; ++c) mine += expf(masked(c) - m);
+  // inclusive scan of the chunk sums over the workgroup
+  float inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_red[wave] = inc;
+  __syncthreads();
+  if (tid == 0) {
+    float run = 0.f;
+    for (int w = 0; w < NT / 64; ++w) { s_pre[w] = run; run += s_red[w]; }
+  }
+  __syncthreads();
+  // [before, upto): this thread's share of the cumulative mass; a thread's `upto` is the next
+  // thread's `before` bit for bit, so the shares tile [0, total) without gaps
+  const float prev = __shfl_up(inc, 1, 64);
+  const float before = s_pre[wave] + (lane == 0 ? 0.f : prev);
+  const float upto = s_pre[wave] + inc;
+  const float total = s_pre[NT / 64 - 1] + s_red[NT / 64 - 1];
+  const float target = p.u[row] * total;
+  if (target >= before && target < upto && c_hi > c_lo) {
+    float run = before;
+    int pick = -1;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float e = expf(masked(c) - m);
+      run += e;
+      if (e > 0.f) {
+        pick = c;                 // (the last column with mass, should rounding overshoot)
+        if (target < run) break;
+      }
+    }
+    if (pick >= 0) atomicMax(&s_pick, pick);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int sample = s_pick;
+    if (sample < 0) {  // rounding left the target beyond the last chunk: the last column with mass
+      for (int c = p.V - 1; c >= 0 && sample < 0; --c)
+        if (expf(masked(c) - m) > 0.f) sample = c;
+      if (sample < 0) sample = 0;
+    }
+    if (p.row_len) {
+      const int len = p.row_len[row];
+      if (p.step + 1 == len) sample = p.eos;
+      if (p.step >= len) sample = p.pad;
+    }
+    p.out[row] = sample;
+  }
+}
+
 }  // namespace
 
 int logit_masks_f32(float* logits, int N, int V, const LogitMasks& mk, hipStream_t s) {
@@ -226,6 +319,23 @@ int logit_masks_f32(float* logits, int N, int V, const LogitMasks& mk, hipStream
   else
     hipLaunchKernelGGL(logit_masks_kernel<false>, grid, dim3(NT), 0, s, logits, N, V, mk);
   ICAP_LAUNCH_CHECK("logit_masks_kernel");
+  return ICAP_OK;
+}
+
+// sample[n] ~ softmax(logits[n] + f32.min at the start / eos / pad columns), drawn by inversion
+// at u[n]; with row_len: eos where step + 1 == row_len[n], pad where step >= row_len[n].
+int sample_categorical_f32(const float* logits, const float* u, const int32_t* row_len, int step,
+                           int start_token, int eos_token, int pad_token, int32_t* samples, int N,
+                           int V, hipStream_t s) {
+  ICAP_REQUIRE(logits && u && samples, "sample_categorical_f32: null pointer");
+  ICAP_REQUIRE(N > 0 && V > 0, "sample_categorical_f32: bad shape");
+  ICAP_REQUIRE(start_token < V && eos_token < V && pad_token < V,
+               "sample_categorical_f32: token outside the vocabulary");
+  ICAP_REQUIRE(!row_len || (eos_token >= 0 && pad_token >= 0),
+               "sample_categorical_f32: eos and pad tokens are required with row lengths");
+  SampleArgs a{logits, u, row_len, samples, V, step, start_token, eos_token, pad_token};
+  hipLaunchKernelGGL(sample_categorical_kernel, dim3(N), dim3(NT), 0, s, a);
+  ICAP_LAUNCH_CHECK("sample_categorical_kernel");
   return ICAP_OK;
 }
 

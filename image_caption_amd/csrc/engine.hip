@@ -51,6 +51,8 @@ int dense_topk_f32(const float*, const float*, const float*, int, int, int, int,
                    const LogitMasks*, hipStream_t);
 int logit_masks_f32(float*, int, int, const LogitMasks&, hipStream_t);
 int expand_rows_i32(const int32_t*, int32_t*, int, int, int, hipStream_t);
+int sample_categorical_f32(const float*, const float*, const int32_t*, int, int, int, int, int32_t*, int,
+                           int, hipStream_t);
 bool beam_records_supported(int W, int half_tiles, int top_k);
 size_t packed_split_bytes(int K, int N);
 int pack_weight_split(const float*, void*, int, int, int, int, int, hipStream_t);
@@ -500,7 +502,7 @@ using namespace icap;
 
 extern "C" {
 
-int icap_version(void) { return 109; }
+int icap_version(void) { return 110; }
 
 size_t icap_last_error(char* buf, size_t len) {
   const std::string& m = last_error();
@@ -642,6 +644,13 @@ int icap_beam_step_rows_f32(const float* logits, const float* log_probs, const u
 }
 
 size_t icap_beam_step_workspace_bytes(int B, int W) { return beam_step_workspace_bytes(B, W); }
+
+int icap_sample_categorical_f32(const float* logits, const float* u, const int32_t* row_len,
+                                int step, int start_token, int eos_token, int pad_token,
+                                int32_t* samples, int N, int V, icap_stream_t stream) {
+  return sample_categorical_f32(logits, u, row_len, step, start_token, eos_token, pad_token,
+                                samples, N, V, (hipStream_t)stream);
+}
 
 int icap_beam_scores_f32(const float* logits, const float* log_probs, const uint8_t* finished,
                          const int32_t* lengths, int eos_token, double length_penalty_weight,

@@ -282,6 +282,21 @@ def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_pena
     return scores, ids, parents, nlp, nfin, nlen
 
 
+def sample_categorical(logits, u, step=0, row_len=None, start_token=-1, eos_token=-1, pad_token=-1,
+                       out=None):
+    """One step of the sequence sampler (reference utils/agent_utils.py:81-125): a draw per row
+    from softmax(logits with f32.min added at the start / eos / pad columns) by inversion of
+    the cumulative distribution at u [N] in [0,1); with row_len [N] the forcing by position
+    (eos where step + 1 == row_len, pad where step >= row_len).  Returns int32 [N]."""
+    N, V = logits.shape
+    if out is None:
+        out = torch.empty(N, dtype=i32, device=logits.device)
+    _lib.call("icap_sample_categorical_f32", _chk(logits, f32, "logits"), _chk(u, f32, "u"),
+              _opt(row_len, i32, "row_len"), int(step), int(start_token), int(eos_token),
+              int(pad_token), _chk(out, i32, "out"), N, V, current_stream())
+    return out
+
+
 def backtrack(ids, parents, last_scores, last_finished):
     """ids/parents [T,B,W] -> (tokens[B,T] i32, best_beam[B] i32, best_score[B] f32)."""
     T, B, W = ids.shape

@@ -1,5 +1,5 @@
-"""Beam-search baseline generator of the sequence-level trainers (reference
-utils/agent_utils.py:30-32,134-284): same class names, constructor arguments and call
+"""Sequence generators of the sequence-level trainers (reference utils/agent_utils.py:30-284):
+the sampler and the beam-search baseline, same class names, constructor arguments and call
 signatures; tensors are torch tensors on the ROCm device."""
 import torch
 
@@ -14,6 +14,72 @@ def sequence_length_fn(sequences, sequence_mask, keepdims=False):
     """Number of tokens greater than the pad token per row (`:30-32`)."""
     flag = (sequences > sequence_mask).to(torch.int32)
     return flag.sum(dim=-1, keepdim=keepdims).to(torch.int32)
+
+
+class SequenceSampler(object):
+    """`:34-132`.  __call__((features, sequences)) -> int32 [B, T], start token first: one
+    draw per row and step from the policy's softmax with the pad, start and eos columns
+    masked, eos forced where the step reaches a row's target length and pad after it.
+
+    The reference draws with `tf.random.categorical`; that random stream is TensorFlow's
+    own, so here each step takes one uniform number per row - from `generator` (a
+    torch.Generator on the device, default: torch's global one) or from
+    `uniform_fn(time_step, batch_size)` -> float32 [B] in [0,1) - and inverts the cumulative
+    distribution at it.  `log_prob_fn` other than log-softmax is applied first and the draw
+    is made from its output."""
+
+    def __init__(self,
+                 action_network,
+                 start_token,
+                 eos_token,
+                 pad_token=0,
+                 log_prob_fn=None,
+                 dtype=torch.int32,
+                 generator=None,
+                 uniform_fn=None):
+        self.action_network = action_network
+        self.start_token = start_token
+        self.pad_token = pad_token
+        self.eos_token = eos_token
+        self.log_prob_fn = log_prob_fn
+        self.data_type = dtype
+        self.generator = generator
+        self.uniform_fn = uniform_fn
+
+    def _uniforms(self, time_step, batch_size, device):
+        if self.uniform_fn is not None:
+            return torch.as_tensor(self.uniform_fn(time_step, batch_size), dtype=torch.float32,
+                                   device=device).contiguous()
+        return torch.rand(batch_size, dtype=torch.float32, device=device, generator=self.generator)
+
+    def __call__(self, inputs, **kwargs):
+        features, sequences = inputs
+        batch_size = sequences.shape[0]
+        device = features.device
+        start_col = torch.full((batch_size, 1), self.start_token, dtype=torch.int32, device=device)
+        row_len = sequence_length_fn(sequences, self.pad_token).contiguous()
+        samples = [start_col]
+        state = self.action_network.reset_state(sequences, {"features": features}, **kwargs)
+        dec_input = start_col[:, 0]
+        for time_step in range(1, sequences.shape[1]):
+            predictions, state = self.action_network((dec_input, {"features": features}, state),
+                                                     **kwargs)
+            predictions = predictions.reshape(batch_size, -1)
+            if not predictions.is_contiguous() or predictions.dtype != torch.float32:
+                predictions = predictions.contiguous().float()
+            if self.log_prob_fn is not None:
+                # a caller-supplied normalisation sees the masked logits, as at `:112-118` (the
+                # draw below masks the same columns again, which leaves their zero mass at zero)
+                for tok in (self.pad_token, self.start_token, self.eos_token):
+                    ops.logit_masks(predictions, start_token=tok)
+                predictions = self.log_prob_fn(predictions).contiguous().float()
+            sample = ops.sample_categorical(predictions, self._uniforms(time_step, batch_size, device),
+                                            step=time_step, row_len=row_len,
+                                            start_token=self.start_token, eos_token=self.eos_token,
+                                            pad_token=self.pad_token)
+            samples.append(sample.reshape(-1, 1))
+            dec_input = sample
+        return torch.cat(samples, dim=-1).to(self.data_type)
 
 
 class BaselineSequeneBeamSearcher(object):

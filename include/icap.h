@@ -426,6 +426,20 @@ int icap_engine_fused_vocab(const icap_engine* engine);
 int icap_engine_kernel_times(icap_engine* engine, float* ms /*[ICAP_K_COUNT]*/,
                              int32_t* launches /*[ICAP_K_COUNT]*/);
 
+/* One sampling step of the sequence sampler of the policy-gradient trainers
+ * (SequenceSampler.__call__, utils/agent_utils.py:81-125): f32.min is added to the start, eos
+ * and pad columns of the logits (negative token: no mask), samples[n] is drawn from the
+ * softmax of row n, and with row_len the reference's forcing applies: eos where
+ * step + 1 == row_len[n], pad where step >= row_len[n] (row_len as sequence_length_fn
+ * gives it).  The reference draws with tf.random.categorical, whose random stream is TF's own;
+ * here the caller supplies one uniform number u[n] in [0,1) per row and the draw is the
+ * inverse of the cumulative distribution at u[n], so the distribution and the forcing are
+ * what can be checked, not the individual draws.  logits[N,V], u[N] f32, row_len[N] i32 or
+ * NULL, samples[N] i32. */
+int icap_sample_categorical_f32(const float* logits, const float* u, const int32_t* row_len,
+                                int step, int start_token, int eos_token, int pad_token,
+                                int32_t* samples, int N, int V, icap_stream_t stream);
+
 /* ---- transformer decoder path ------------------------------------------------------
  * decoder/transform_decoder.py + attention/attention.py:160-562 + decoder/ffn_layer.py +
  * embedding/position_embedding.py, run incrementally: one pass of the layer stack per new

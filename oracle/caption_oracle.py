@@ -468,6 +468,56 @@ def sequence_length_fn(sequences, sequence_mask, keepdims=False):
     return np.sum(flag, axis=-1, keepdims=keepdims)
 
 
+def sample_categorical(logits, u, step=0, row_len=None, start_token=-1, eos_token=-1, pad_token=-1):
+    """One step of `SequenceSampler.__call__` (`utils/agent_utils.py:81-125`): f32.min added at
+    the pad / start / eos columns, softmax, a draw per row, then eos where step + 1 == length
+    and pad where step >= length.  `tf.random.categorical` is replaced by the inverse of the
+    cumulative distribution (float64) at the given uniform numbers u [N]."""
+    x = np.array(logits, dtype=np.float32, copy=True)
+    for tok in (pad_token, start_token, eos_token):
+        if tok >= 0:
+            with np.errstate(over="ignore"):
+                x[:, tok] = x[:, tok] + np.float32(F32_MIN)
+    e = np.exp((x - x.max(axis=1, keepdims=True)).astype(np.float64))
+    cdf = np.cumsum(e, axis=1)
+    target = np.asarray(u, dtype=np.float64) * cdf[:, -1]
+    out = np.empty(x.shape[0], np.int32)
+    for n in range(x.shape[0]):
+        c = int(np.searchsorted(cdf[n], target[n], side="right"))
+        c = min(c, x.shape[1] - 1)
+        while e[n, c] == 0.0 and c > 0:      # (a column without mass is never drawn)
+            c -= 1
+        out[n] = c
+    if row_len is not None:
+        ln = np.asarray(row_len)
+        out = np.where(step + 1 == ln, np.int32(eos_token), out)
+        out = np.where(step >= ln, np.int32(pad_token), out).astype(np.int32)
+    return out
+
+
+def sequence_sampler(p, features, sequences, uniforms, start_token, eos_token, pad_token=0,
+                     cell="lstm", reset_state_from_feat=1):
+    """`SequenceSampler.__call__` (`utils/agent_utils.py:52-132`) over `RnnDecoderNetwork(decoder)`:
+    T - 1 decoder steps from the start token, one draw per row and step (uniforms [T-1, B],
+    see `sample_categorical`).  Returns int32 [B, T], start token first."""
+    step_fn = lstm_decoder_step if cell == "lstm" else gru_decoder_step
+    reset_fn = reset_state if cell == "lstm" else reset_state_gru
+    sequences = np.asarray(sequences)
+    B, T = sequences.shape
+    row_len = sequence_length_fn(sequences, pad_token)
+    hidden = reset_fn(p, B, features, reset_state_from_feat)
+    dec_input = np.full([B, 1], start_token, np.int32)
+    samples = [dec_input.copy()]
+    for t in range(1, T):
+        logits, hidden, _, _ = step_fn(p, dec_input, features, hidden)
+        sample = sample_categorical(logits, uniforms[t - 1], step=t, row_len=row_len,
+                                    start_token=start_token, eos_token=eos_token,
+                                    pad_token=pad_token)
+        samples.append(sample.reshape(-1, 1))
+        dec_input = sample.reshape(-1, 1)
+    return np.concatenate(samples, axis=1).astype(np.int32)
+
+
 def baseline_sequence_beam_search(p, features, sequences, beam_width, vocab_size, max_length,
                                   start_token, eos_token, pad_token=0, cell="lstm",
                                   reset_state_from_feat=1, return_trace=False):
