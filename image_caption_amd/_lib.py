@@ -16,6 +16,7 @@ TILE_REFERENCE, TILE_REPEAT = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F32_SPLIT = 0, 1, 2
 CELL_LSTM, CELL_GRU = 0, 1
 MAX_BEAM_WIDTH = 16
+BEAM_STEP_STATIC_MAX_ROWS = 16384
 K_NAMES = ("encode", "feat_proj", "init_state", "attn_query", "attention", "lstm", "fc1",
            "vocab", "beam", "backtrack")
 
@@ -97,6 +98,8 @@ SIGNATURES = {
     "icap_beam_step_rows_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                                  _I, _I, _I, _I, _P, C.c_size_t, _P], C.c_int),
     "icap_beam_step_workspace_bytes": ([_I, _I], C.c_size_t),
+    "icap_beam_step_static_f32": ([_P, _P, _P, _P, _I, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
+                                   _I, _I, _I, _P], C.c_int),
     "icap_sample_categorical_f32": ([_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
     "icap_backtrack": ([_P] * 7 + [_I, _I, _I, _P], C.c_int),
     "icap_packed_weight_bytes": ([_I, _I], C.c_size_t),

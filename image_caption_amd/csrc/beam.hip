@@ -21,6 +21,8 @@
 // logits streamed twice.
 #include <math.h>
 
+#include <mutex>
+
 #include "beam_shared.h"
 #include "icap_common.h"
 
@@ -865,6 +867,61 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
                             length_penalty_weight, input_is_log_prob, scores, predicted_ids,
                             parent_ids, next_log_probs, next_finished, next_lengths, B, W, W, V,
                             workspace, workspace_bytes, s);
+}
+
+// ---- the beam step for callers that cannot allocate -------------------------------------
+// Same kernels as beam_step_f32; the candidate workspace is a fixed array in device memory
+// instead of a caller buffer.  Every GPU the library runs on holds its own copy of the array
+// (at its own address) until the process ends.
+constexpr size_t STATIC_WS_BYTES =
+    (size_t)ICAP_BEAM_STEP_STATIC_MAX_ROWS * (sizeof(float2) + 3 * WL_MAX * sizeof(float));
+static __device__ __align__(256) unsigned char scratch[STATIC_WS_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_mutex;
+void* scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` per device ordinal
+
+// The device address of the array on the current device, looked up once per device (the
+// array's name is only a host-side handle; kernels get this pointer as an argument).
+int static_scratch(void** out) {
+  int dev = -1;
+  ICAP_HIP(hipGetDevice(&dev));
+  ICAP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "beam_step_static_f32: device ordinal %d not served",
+               dev);
+  std::lock_guard<std::mutex> lock(scratch_mutex);
+  if (!scratch_ptr[dev]) {
+    void* p = nullptr;
+    ICAP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ICAP_REQUIRE(p != nullptr, "beam_step_static_f32: no device address for the static workspace");
+    scratch_ptr[dev] = p;
+  }
+  *out = scratch_ptr[dev];
+  return ICAP_OK;
+}
+}  // namespace
+
+int beam_step_static_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                         const int32_t* lengths, int time, int start_offset, int eos_token,
+                         double length_penalty_weight, int input_is_log_prob, float* scores,
+                         int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                         uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
+                         hipStream_t s) {
+  ICAP_REQUIRE(B > 0 && W > 0, "beam_step_static_f32: bad shape");
+  if ((long long)B * W > ICAP_BEAM_STEP_STATIC_MAX_ROWS)
+    return fail(ICAP_ERR_UNSUPPORTED,
+                "beam_step_static_f32: %lld rows (B*W) exceed the static workspace of %d rows; use "
+                "icap_beam_step_f32 with a caller workspace",
+                (long long)B * W, ICAP_BEAM_STEP_STATIC_MAX_ROWS);
+  void* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != ICAP_OK) return rc;
+  // every slot the merge kernel reads is written by the row kernel of the same call (statistics
+  // and all WL candidate slots of every row, empty ones marked), so nothing needs clearing
+  return beam_step_rows_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
+                            length_penalty_weight, input_is_log_prob, scores, predicted_ids,
+                            parent_ids, next_log_probs, next_finished, next_lengths, B, W, W, V, ws,
+                            STATIC_WS_BYTES, s);
 }
 
 // Records one workgroup can hold in registers (8 per thread); more take the unfused kernels.

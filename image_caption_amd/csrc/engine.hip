@@ -95,6 +95,9 @@ int beam_step_rows_f32(const float*, const float*, const uint8_t*, const int32_t
                        double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
                        int, int, void*, size_t, hipStream_t);
 size_t beam_step_workspace_bytes(int B, int W);
+int beam_step_static_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
+                         double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
+                         int, hipStream_t);
 int beam_scores_f32(const float*, const float*, const uint8_t*, const int32_t*, int, double, int,
                     float*, float*, int, int, int, hipStream_t);
 int beam_gather_f32(const float*, const uint8_t*, const int32_t*, const int32_t*, int, int32_t*,
@@ -644,6 +647,18 @@ int icap_beam_step_rows_f32(const float* logits, const float* log_probs, const u
 }
 
 size_t icap_beam_step_workspace_bytes(int B, int W) { return beam_step_workspace_bytes(B, W); }
+
+int icap_beam_step_static_f32(const float* logits, const float* log_probs, const uint8_t* finished,
+                              const int32_t* lengths, int time, int start_offset, int eos_token,
+                              double length_penalty_weight, int input_is_log_prob, float* scores,
+                              int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
+                              uint8_t* next_finished, int32_t* next_lengths, int B, int W, int V,
+                              icap_stream_t stream) {
+  return beam_step_static_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
+                              length_penalty_weight, input_is_log_prob, scores, predicted_ids,
+                              parent_ids, next_log_probs, next_finished, next_lengths, B, W, V,
+                              (hipStream_t)stream);
+}
 
 int icap_sample_categorical_f32(const float* logits, const float* u, const int32_t* row_len,
                                 int step, int start_token, int eos_token, int pad_token,

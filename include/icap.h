@@ -232,6 +232,24 @@ int icap_beam_step_rows_f32(const float* logits, const float* log_probs,
                             int32_t* next_lengths, int B, int R, int W, int V,
                             void* workspace, size_t workspace_bytes, icap_stream_t stream);
 
+/* icap_beam_step_f32 for callers that cannot allocate device memory or hand over a
+ * workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference.  Same arguments, arithmetic and results as
+ * icap_beam_step_f32 without the workspace pair: the candidate workspace is a fixed array
+ * in device memory (ICAP_BEAM_STEP_STATIC_MAX_ROWS rows of 200 bytes = 3.2 MB, held by every
+ * GPU the library runs on until the process ends).  B*W above that limit returns
+ * ICAP_ERR_UNSUPPORTED.  The call allocates nothing; the first call on a device looks the
+ * array's device address up once.  All calls on one GPU share the array: calls that overlap
+ * in time on one GPU (two streams) race - order them or use icap_beam_step_f32. */
+#define ICAP_BEAM_STEP_STATIC_MAX_ROWS 16384
+int icap_beam_step_static_f32(const float* logits, const float* log_probs,
+                              const uint8_t* finished, const int32_t* lengths,
+                              int time, int start_offset, int eos_token,
+                              double length_penalty_weight, int input_is_log_prob,
+                              float* scores, int32_t* predicted_ids, int32_t* parent_ids,
+                              float* next_log_probs, uint8_t* next_finished,
+                              int32_t* next_lengths, int B, int W, int V, icap_stream_t stream);
+
 /* The beam-search step in two halves, for a caller-supplied successor choice
  * (BeamSearchConfig.choose_successors_fn other than choose_top_k).
  * icap_beam_scores_f32 materialises, for every (image, beam, word),

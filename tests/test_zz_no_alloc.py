@@ -1,0 +1,96 @@
+"""icap_beam_step_static_f32 (the beam step for callers that cannot allocate: its candidate
+workspace is a fixed array in device memory) against icap_beam_step_f32 with a caller
+workspace, through the C ABI: every output bit for bit, on two calls in a row, the second
+with a smaller input, plus the oracle on the same inputs and the size limit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caption_oracle as co
+from tests.helpers import dev, np_of, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, B, W, V, time):
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((B, W, V)) * 3).astype(np.float32)
+    if time == 0:
+        lp = np.zeros((B, W), np.float32)
+        fin = np.zeros((B, W), bool)
+        lens = np.zeros((B, W), np.int32)
+    else:
+        lp = -np.abs(rng.standard_normal((B, W)) * 4).astype(np.float32)
+        fin = rng.random((B, W)) < 0.3
+        lens = rng.integers(1, 9, size=(B, W)).astype(np.int32)
+    return logits, lp, fin, lens
+
+
+def _outputs(B, W):
+    d = dev()
+    return [torch.empty(B, W, dtype=torch.float32, device=d), torch.empty(B, W, dtype=torch.int32, device=d),
+            torch.empty(B, W, dtype=torch.int32, device=d), torch.empty(B, W, dtype=torch.float32, device=d),
+            torch.empty(B, W, dtype=torch.uint8, device=d), torch.empty(B, W, dtype=torch.int32, device=d)]
+
+
+def _run_both(lib, seed, B, W, V, time, eos, lpw):
+    from image_caption_amd import _lib, ops
+    logits, lp, fin, lens = _case(seed, B, W, V, time)
+    d_logits, d_lp = to_dev(logits), to_dev(lp)
+    d_fin, d_len = to_dev(fin.astype(np.uint8)), to_dev(lens)
+    stream = ops.current_stream()
+    need = int(lib.icap_beam_step_workspace_bytes(B, W))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    ref = _outputs(B, W)
+    _lib.check(lib.icap_beam_step_f32(d_logits.data_ptr(), d_lp.data_ptr(), d_fin.data_ptr(),
+                                      d_len.data_ptr(), time, 0, eos, lpw, 0,
+                                      *[t.data_ptr() for t in ref], B, W, V, ws.data_ptr(), need, stream))
+    got = _outputs(B, W)
+    for t in got:                       # nothing may survive from an earlier call
+        t.fill_(113)
+    free_before = torch.cuda.mem_get_info()[0]
+    _lib.check(lib.icap_beam_step_static_f32(d_logits.data_ptr(), d_lp.data_ptr(), d_fin.data_ptr(),
+                                             d_len.data_ptr(), time, 0, eos, lpw, 0,
+                                             *[t.data_ptr() for t in got], B, W, V, stream))
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    names = ("scores", "ids", "parents", "next_log_probs", "next_finished", "next_lengths")
+    for n, a, b in zip(names, got, ref):
+        np.testing.assert_array_equal(np_of(a).view(np.uint8), np_of(b).view(np.uint8),
+                                      err_msg="%s (B=%d W=%d V=%d time=%d)" % (n, B, W, V, time))
+    # and the oracle on the same inputs: integer outputs exact
+    cfg = co.BeamSearchConfig(W, V, eos, lpw, co.choose_top_k)
+    out, st = co.beam_search_step_batch(time, logits, co.BeamSearchState(lp, fin, lens), cfg)
+    np.testing.assert_array_equal(np_of(got[1]), out.predicted_ids)
+    np.testing.assert_array_equal(np_of(got[2]), out.beam_parent_ids)
+    np.testing.assert_array_equal(np_of(got[4]).astype(bool), st.finished)
+    np.testing.assert_array_equal(np_of(got[5]), st.lengths)
+    return free_before, free_after
+
+
+def test_static_workspace_beam_step_matches_caller_workspace_twice_in_a_row():
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    # first a large call (every slot of the shared array it needs gets written) ...
+    _run_both(lib, 1, B=96, W=10, V=5000, time=3, eos=4, lpw=1.0)
+    # ... then a smaller one right behind it on the same GPU: stale contents of the first
+    # call must not leak into it
+    before, after = _run_both(lib, 2, B=7, W=3, V=1003, time=2, eos=0, lpw=1.2)
+    assert after >= before, "the no-allocation entry point changed the free device memory"
+    # time 0 (one ranked row per image) and the greedy width
+    _run_both(lib, 3, B=5, W=5, V=640, time=0, eos=4, lpw=1.0)
+    _run_both(lib, 4, B=33, W=1, V=10000, time=1, eos=4, lpw=1.0)
+
+
+def test_static_workspace_beam_step_rejects_sizes_beyond_its_array():
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    B, W, V = _lib.BEAM_STEP_STATIC_MAX_ROWS // 16 + 1, 16, 32
+    t = torch.zeros(16, dtype=torch.float32, device=dev())      # never touched: the size check comes first
+    p = t.data_ptr()
+    rc = lib.icap_beam_step_static_f32(p, p, p, p, 1, 0, 4, 1.0, 0, p, p, p, p, p, p, B, W, V, None)
+    assert rc == -3
+    assert "static workspace" in _lib.last_error()
+    # the largest size it takes: B*W == the limit (small vocabulary keeps the logits small)
+    B = _lib.BEAM_STEP_STATIC_MAX_ROWS // 16
+    _run_both(lib, 5, B=B, W=16, V=32, time=1, eos=4, lpw=1.0)
