@@ -2,11 +2,18 @@
 """Headline benchmark: captions/sec of the whole-sequence beam-search decode
 (beam 3, 20 steps, B=512 images per GPU, fp32) on N MI355X GPUs of one node.
 
-A "step" is one pass of the hot path over one batch: encoder -> tile -> reset_state
+One pass of the hot path over one batch of 512 images: encoder -> tile -> reset_state
 -> 20 x (attention, LSTM step, fc1, vocab projection, fused beam step) -> back-track,
-with the synthetic CNN features already resident in HBM.  With N > 1 every rank
-decodes its own 512 images (weak scaling, weights replicated) and the decoded
-sequences are all-gathered over RCCL at the end of every step.
+with the synthetic CNN features already resident in HBM.  A pass takes about 5 ms, so a
+bench "step" is `--inner` passes back to back over that many different resident batches
+(default 10 for the recurrent configurations: 20 steps time about one second instead of a
+tenth of one); `value` counts every caption of every pass.  With N > 1 every rank decodes
+its own batches (weak scaling, weights replicated, no per-step communication) and the decoded
+sequences are all-gathered over RCCL at the end of every pass.
+
+`python bench.py --gpus N` with N > 1 starts its own N ranks (child processes, one per GPU,
+started before anything touches a GPU) unless it already runs under torch.distributed.run
+(WORLD_SIZE set), in which case it is one of the ranks.
 
 Prints ONE JSON line on rank 0."""
 import argparse
@@ -49,6 +56,8 @@ CONFIGS = {
     "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
                              precision="fp32"),
 }
+# passes per bench step (see the module docstring): sized so that 20 steps time about a second
+DEFAULT_INNER = {"transformer_b1024_fp32": 1, "beam10_v50k_fp32": 2}
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32-input MFMA peak of MI355X
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -238,6 +247,29 @@ def cpu_baseline_transformer(cfg, budget_s=12.0):
                       "%.1f s" % (reps, Bs, cfg["W"], cfg["T"], cfg["layers"], cfg["V"], el)}
 
 
+def spawn_ranks(n):
+    """Starts this script once per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, rendezvous on 127.0.0.1) and waits for all of them.  The parent has not
+    touched a GPU: it only starts children and returns the worst exit code; rank 0 prints the
+    JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    worst = max(rcs, key=abs)
+    if worst:
+        raise SystemExit("bench rank exit codes: %s" % rcs)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,7 +278,18 @@ def main():
     ap.add_argument("--config", default="beam3_b512_fp32", choices=sorted(CONFIGS))
     ap.add_argument("--tile-mode", default="reference", choices=["reference", "repeat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inner", type=int, default=0,
+                    help="decode passes per bench step (0: the configuration's default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --ranks-share-gpu rehearses the multi-rank path on one GPU")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="every rank uses cuda:0 (rehearsal on a one-GPU box, gloo only)")
     args = ap.parse_args()
+    if args.inner <= 0:
+        args.inner = DEFAULT_INNER.get(args.config, 10)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import torch.distributed as dist
     from image_caption_amd import synthetic
@@ -257,12 +300,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if args.ranks_share_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("--ranks-share-gpu needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(CONFIGS[args.config])
     precision = cfg.pop("precision")
@@ -275,24 +325,29 @@ def main():
     ccfg = CaptionConfig(start_id=3, eos_id=4, length_penalty_weight=1.0, tile_mode=args.tile_mode,
                          precision=precision, **cfg)
     eng = CaptionEngine(ccfg, p, device=device)
-    img = torch.from_numpy(synthetic.make_images(100 + rank, cfg["B"], cfg["L"], cfg["F"])).to(device)
+    # `inner` different batches per rank, all resident in HBM before anything is timed
+    inner = args.inner
+    imgs = [torch.from_numpy(synthetic.make_images(100 + rank * 1000 + j, cfg["B"], cfg["L"],
+                                                   cfg["F"])).to(device) for j in range(inner)]
+    img = imgs[0]
     tokens = torch.empty(cfg["B"], cfg["T"], dtype=torch.int32, device=device)
     scores = torch.empty(cfg["B"], dtype=torch.float32, device=device)
 
     feats = None
     if loop == "searcher":      # the searcher starts from encoded features [B,L,D], resident in HBM
         from image_caption_amd import ops
-        feats = ops.dense(img.reshape(-1, cfg["F"]), eng.weights["enc_kernel"], eng.weights["enc_bias"],
-                          act=ops.ACT_RELU).reshape(cfg["B"], cfg["L"], cfg["D"]).contiguous()
+        feats = [ops.dense(im.reshape(-1, cfg["F"]), eng.weights["enc_kernel"], eng.weights["enc_bias"],
+                           act=ops.ACT_RELU).reshape(cfg["B"], cfg["L"], cfg["D"]).contiguous()
+                 for im in imgs]
 
     def step():
-        if loop == "searcher":
-            eng.search_baseline(feats, out=tokens, scores=scores)
-        else:
-            eng.decode(img, out=tokens, scores=scores)
-        if world > 1:
-            return all_gather_sequences(tokens)
-        return tokens
+        for j in range(inner):
+            if loop == "searcher":
+                eng.search_baseline(feats[j], out=tokens, scores=scores)
+            else:
+                eng.decode(imgs[j], out=tokens, scores=scores)
+            out = all_gather_sequences(tokens) if world > 1 else tokens
+        return out
 
     def sync():
         if world > 1:
@@ -306,7 +361,7 @@ def main():
     # vocab projection) are bracketed by HIP events on the decode stream inside it - in every
     # fifth decode, an event pair costs the stream a few microseconds per launch; they feed
     # the roofline object. ----
-    eng.set_timing(["vocab"], every=5 if args.steps >= 10 else 1)   # a sample of the decodes
+    eng.set_timing(["vocab"], every=5 if args.steps * inner >= 10 else 1)   # a sample of the decodes
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -315,7 +370,8 @@ def main():
     vocab_ms, vocab_n = eng.kernel_times()["vocab"]
     eng.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == cfg["B"] * world
@@ -324,17 +380,17 @@ def main():
     # that each class is timed alone (not part of `value`)
     eng.set_overlap(False)
     eng.set_timing(True)
-    for _ in range(min(args.steps, 5)):
+    for _ in range(min(args.steps, 5) if inner == 1 else 1):
         step()
     sync()
-    diag_steps = min(args.steps, 5)
+    diag_steps = min(args.steps, 5) if inner == 1 else inner     # decodes in the diagnostic pass
     ktimes = eng.kernel_times()
     eng.set_timing(False)
     eng.set_overlap(True)
 
     if rank == 0:
         N = cfg["B"] * cfg["W"]
-        captions = cfg["B"] * world * args.steps
+        captions = cfg["B"] * world * args.steps * inner
         value = captions / elapsed
         # dominant kernel: the vocab projection  [N,H] x [H,V].  On f32 MFMA it is bound by the
         # matrix pipe; with bf16 operands the matrix work shrinks 16x and the fp32 logits
@@ -392,7 +448,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32_split": "f32 (3 x bf16 split operands, f32 accumulate)"}.get(precision, "f32"),
             "data": "synthetic",
-            "config": {"workload": args.config, "images_per_gpu": cfg["B"], "beam_width": cfg["W"],
+            "config": {"workload": args.config, "images_per_gpu": cfg["B"],
+                       "decode_passes_per_step": inner, "captions_per_step": cfg["B"] * inner * world,
+                       "beam_width": cfg["W"],
                        "decode_steps": cfg["T"], "locations": cfg["L"], "feature_dim": cfg["F"],
                        "hidden": cfg["H"], "vocab": cfg["V"], "tile_mode": args.tile_mode,
                        "sharding": "images split over ranks, all-gather of sequences"},
@@ -402,8 +460,12 @@ def main():
                             else "logits read once",
                             "beam_step_bytes": int(beam_bytes), "attention_GBps": round(att_gbs, 1),
                             "peak_GBps": PEAK_HBM_GBS},
-            "kernel_ms_per_step": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
+            "kernel_ms_per_decode_pass": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
+            "ms_per_decode_pass": round(elapsed / args.steps / inner * 1e3, 4),
         }
+        if world > 1:
+            line["world_size_reported_by_backend"] = dist.get_world_size()
+            line["backend"] = args.backend
         if world == 1 and precision == "fp32" and loop == "decode" and not args.no_cpu_baseline:
             # informational, not `value`: the same workload with the opt-in precision modes
             # (measured before the CPU baseline, while the GPU clocks are still up)

@@ -159,8 +159,9 @@ struct icap_engine {
   int timing_every = 1;      // bracket every n-th decode call
   long decode_calls = 0;     // since the mask was set
   struct Span { int cls; hipEvent_t a, b; };
-  std::vector<Span> spans;
+  std::vector<Span> spans;   // event pool, reserved by icap_engine_set_timing
   size_t spans_used = 0;
+  size_t spans_dropped = 0;  // launches that found the pool used up
 };
 
 namespace icap {
@@ -205,6 +206,9 @@ int check_config(const icap_config& c) {
   return ICAP_OK;
 }
 
+// Brackets one launch with a pair of events from the pool that icap_engine_set_timing
+// reserved; a decode never creates events (it may run under graph capture and promises not to
+// allocate).  When the pool is used up, later launches go unbracketed and are counted as dropped.
 struct Timed {
   icap_engine* e;
   hipStream_t s;
@@ -213,13 +217,9 @@ struct Timed {
   Timed(icap_engine* e_, int cls, hipStream_t s_) : e(e_), s(s_), on(((e_->timing >> cls) & 1u) != 0) {
     if (!on) return;
     if (e->spans_used == e->spans.size()) {
-      icap_engine::Span sp;
-      sp.cls = cls;
-      if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
-        on = false;
-        return;
-      }
-      e->spans.push_back(sp);
+      e->spans_dropped++;
+      on = false;
+      return;
     }
     idx = e->spans_used++;
     e->spans[idx].cls = cls;
@@ -806,10 +806,6 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
-  if (err == hipSuccess)
-    err = hipMemcpy(&e->att_v_bias, weights->att_v_bias, sizeof(float), hipMemcpyDeviceToHost);
-  if (err == hipSuccess)
-    err = hipMemcpy(&e->fc3_bias, weights->fc3_bias, sizeof(float), hipMemcpyDeviceToHost);
   if (err == hipSuccess) {
     // The side stream carries work that is off the critical path: give it the lowest
     // priority so that its workgroups fill the compute units the main stream leaves idle
@@ -929,8 +925,14 @@ int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
   }
   // emb_proj[v] = embedding[v] . lstm_kernel[D:D+E]: the part of the LSTM gates that
   // depends only on the input token, hoisted out of the step loop
-  return engine_dense(e, icap_engine::PK_LSTM_EMB, w.embedding, emb_rows, nullptr, e->emb_proj, c.V,
-                      c.E, 4 * c.H, ICAP_ACT_NONE, s);
+  ICAP_TRY(engine_dense(e, icap_engine::PK_LSTM_EMB, w.embedding, emb_rows, nullptr, e->emb_proj, c.V,
+                        c.E, 4 * c.H, ICAP_ACT_NONE, s));
+  // the two scalar biases travel to the kernels by value: read them back (ordered behind
+  // whatever wrote them on this stream; this is the one call that waits for its stream)
+  ICAP_HIP(hipMemcpyAsync(&e->att_v_bias, w.att_v_bias, sizeof(float), hipMemcpyDeviceToHost, s));
+  ICAP_HIP(hipMemcpyAsync(&e->fc3_bias, w.fc3_bias, sizeof(float), hipMemcpyDeviceToHost, s));
+  ICAP_HIP(hipStreamSynchronize(s));
+  return ICAP_OK;
 }
 
 int icap_engine_destroy(icap_engine* e) {
@@ -953,7 +955,6 @@ size_t icap_engine_workspace_bytes(const icap_engine* e) { return e ? e->ws_byte
 int icap_decode(icap_engine* e, const float* img, int32_t* tokens, float* best_score,
                 icap_stream_t stream) {
   ICAP_REQUIRE(e && img && tokens, "icap_decode: null argument");
-  if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;  // bound the event pool
   return decode_impl(e, img, tokens, best_score, (hipStream_t)stream);
 }
 
@@ -964,7 +965,6 @@ int icap_search_baseline(icap_engine* e, const float* features, const int32_t* s
                "icap_search_baseline: pad token outside the vocabulary");
   ICAP_REQUIRE(!seq_len || (e->cfg.eos_id >= 0 && e->cfg.eos_id < e->cfg.V),
                "icap_search_baseline: forced eos needs an eos token inside the vocabulary");
-  if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;
   LoopVariant lv;
   lv.features = features;
   lv.seq_len = seq_len;
@@ -999,10 +999,26 @@ int icap_engine_trace(const icap_engine* e, int32_t* ids, int32_t* parents, floa
 
 int icap_engine_set_timing(icap_engine* e, unsigned class_mask) {
   ICAP_REQUIRE(e, "icap_engine_set_timing: null engine");
+  if (class_mask) {
+    // launches a decode can bracket: a few once-per-decode classes plus at most seven per step;
+    // the pool serves ICAP_TIMING_POOL_DECODES bracketed decodes between two reads
+    const size_t want = (size_t)ICAP_TIMING_POOL_DECODES * (8 + 7 * (size_t)e->cfg.T);
+    while (e->spans.size() < want) {
+      icap_engine::Span sp;
+      sp.cls = 0;
+      sp.a = sp.b = nullptr;
+      if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
+        if (sp.a) (void)hipEventDestroy(sp.a);
+        return fail(ICAP_ERR_HIP, "icap_engine_set_timing: cannot create the timing events");
+      }
+      e->spans.push_back(sp);
+    }
+  }
   e->timing_mask = class_mask;
   e->timing = class_mask;
   e->decode_calls = 0;
   e->spans_used = 0;
+  e->spans_dropped = 0;
   return ICAP_OK;
 }
 

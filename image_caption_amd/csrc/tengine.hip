@@ -126,6 +126,8 @@ struct icap_tengine {
 namespace icap {
 namespace {
 
+// Brackets one launch with a pair of events from the pool that icap_tengine_set_timing
+// reserved; a decode never creates events.  Launches that find the pool used up go unbracketed.
 struct TTimed {
   icap_tengine* e;
   hipStream_t s;
@@ -134,13 +136,8 @@ struct TTimed {
   TTimed(icap_tengine* e_, int cls, hipStream_t s_) : e(e_), s(s_), on(((e_->timing >> cls) & 1u) != 0) {
     if (!on) return;
     if (e->spans_used == e->spans.size()) {
-      icap_tengine::Span sp;
-      sp.cls = cls;
-      if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
-        on = false;
-        return;
-      }
-      e->spans.push_back(sp);
+      on = false;
+      return;
     }
     idx = e->spans_used++;
     e->spans[idx].cls = cls;
@@ -454,7 +451,6 @@ size_t icap_tengine_workspace_bytes(const icap_tengine* e) { return e ? e->ws_by
 int icap_tdecode(icap_tengine* e, const float* img, int32_t* tokens, float* best_score,
                  icap_stream_t stream) {
   ICAP_REQUIRE(e && img && tokens, "icap_tdecode: null argument");
-  if (e->timing && e->spans_used > (size_t)1 << 20) e->spans_used = 0;
   return tdecode_impl(e, img, tokens, best_score, (hipStream_t)stream);
 }
 
@@ -479,6 +475,23 @@ int icap_tengine_last_output(const icap_tengine* e, float* out, icap_stream_t st
 
 int icap_tengine_set_timing(icap_tengine* e, unsigned class_mask) {
   ICAP_REQUIRE(e, "icap_tengine_set_timing: null engine");
+  if (class_mask) {
+    // per decode: T + 1 passes of the stack (eleven launches per layer, three around it) plus
+    // the once-per-decode classes; the pool serves ICAP_TTIMING_POOL_DECODES decodes
+    const size_t per_decode =
+        8 + ((size_t)e->cfg.T + 1) * (11 * (size_t)e->cfg.layers + 5);
+    const size_t want = (size_t)ICAP_TTIMING_POOL_DECODES * per_decode;
+    while (e->spans.size() < want) {
+      icap_tengine::Span sp;
+      sp.cls = 0;
+      sp.a = sp.b = nullptr;
+      if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) {
+        if (sp.a) (void)hipEventDestroy(sp.a);
+        return fail(ICAP_ERR_HIP, "icap_tengine_set_timing: cannot create the timing events");
+      }
+      e->spans.push_back(sp);
+    }
+  }
   e->timing = class_mask;
   e->spans_used = 0;
   return ICAP_OK;

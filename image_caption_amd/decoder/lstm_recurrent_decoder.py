@@ -184,11 +184,14 @@ class LstmDecoder(Decoder):
         return type(self)(**self.args)
 
     def create_variables(self):
+        """One step on zero inputs of the smallest shape, which builds every variable, and
+        returns that step's outputs like the reference (`:136-140`): (logits[1,V], [h,c],
+        weights[1,1,1], context[1,embedding_dim])."""
         dev = self.device or default_device()
-        self._build(self.embedding_dim, dev)
-        if isinstance(self.embedding_layer, EmbeddingLayer):
-            self.embedding_layer.table  # noqa: B018  builds the table
-        return None
+        dec_input = torch.zeros((1,), dtype=torch.int32, device=dev)
+        feats = torch.zeros((1, 1, self.embedding_dim), dtype=torch.float32, device=dev)
+        hidden = self.reset_state(dec_input, {})
+        return self.call((dec_input, {"features": feats}, hidden), training=False)
 
     # -- weight import / export with the .npz container's parameter names --
     def load_params(self, p, device=None):

@@ -35,8 +35,15 @@ def all_gather_sequences(tokens, total=None, group=None):
     if tokens.shape[0] != cap:
         send = torch.zeros(cap, T, dtype=tokens.dtype, device=tokens.device)
         send[:tokens.shape[0]] = tokens
-    out = torch.empty(world * cap, T, dtype=tokens.dtype, device=tokens.device)
-    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # rehearsal of the multi-rank path without RCCL (ranks sharing one GPU, CPU-only
+        # boxes): gloo gathers host tensors
+        host = torch.empty(world * cap, T, dtype=tokens.dtype)
+        dist.all_gather_into_tensor(host, send.contiguous().cpu(), group=group)
+        out = host.to(tokens.device)
+    else:
+        out = torch.empty(world * cap, T, dtype=tokens.dtype, device=tokens.device)
+        dist.all_gather_into_tensor(out, send.contiguous(), group=group)
     if all(s == cap for s in sizes):
         return out
     parts = [out[r * cap:r * cap + sizes[r]] for r in range(world)]

@@ -105,6 +105,31 @@ class CaptionEngine:
         with torch.cuda.device(self.device):
             _lib.check(lib.icap_engine_create(C.byref(c), C.byref(w), C.byref(handle)))
         self._handle = handle
+        self._versions = self._weight_versions()
+
+    def _weight_versions(self):
+        return {k: t._version for k, t in self.weights.items()}
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def refresh_weights(self):
+        """Recomputes what the engine derives from the weights (token part of the gates, GRU
+        re-layout, packed bf16 / split copies, the two scalar biases) after their values were
+        changed in place.  Waits for the current stream."""
+        with torch.cuda.device(self.device):
+            _lib.call("icap_engine_refresh_weights", self._handle, self._stream())
+        self._versions = self._weight_versions()
+
+    def refresh_if_stale(self):
+        """The engine points at the caller's weight tensors (no copy when they already are
+        float32 on the device).  Every decode compares their torch version counters with the
+        ones seen at the last refresh, so an optimizer step or `kernel.copy_()` between two
+        decodes is picked up; writes that bypass torch need an explicit refresh_weights()."""
+        if self._weight_versions() != self._versions:
+            self.refresh_weights()
+            return True
+        return False
 
     def _check_shapes(self):
         c, w = self.config, self.weights
@@ -149,10 +174,17 @@ class CaptionEngine:
             out = torch.empty(c.B, c.T, dtype=torch.int32, device=self.device)
         if scores is None:
             scores = torch.empty(c.B, dtype=torch.float32, device=self.device)
-        _lib.call("icap_decode", self._handle, ops._chk(img, torch.float32, "img"),
+        self._same_device(img=img, out=out, scores=scores)
+        self.refresh_if_stale()
+        ops._call("icap_decode", self._handle, ops._chk(img, torch.float32, "img"),
                   ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
                   ops.current_stream())
         return out, scores
+
+    def _same_device(self, **tensors):
+        for name, t in tensors.items():
+            if t is not None and isinstance(t, torch.Tensor) and t.is_cuda and t.device != self.device:
+                raise ValueError("%s lives on %s, the engine on %s" % (name, t.device, self.device))
 
     def search_baseline(self, features, seq_len=None, pad_token=0, out=None, scores=None):
         """The baseline beam searcher's loop (reference utils/agent_utils.py:152-262) on
@@ -167,7 +199,10 @@ class CaptionEngine:
             scores = torch.empty(c.B, dtype=torch.float32, device=self.device)
         if seq_len is not None and tuple(seq_len.shape) != (c.B,):
             raise ValueError("seq_len must have shape (%d,)" % c.B)
-        _lib.call("icap_search_baseline", self._handle, ops._chk(features, torch.float32, "features"),
+        self._same_device(features=features, seq_len=seq_len, out=out, scores=scores)
+        self.refresh_if_stale()
+        ops._call("icap_search_baseline", self._handle,
+                  ops._chk(features, torch.float32, "features"),
                   ops._opt(seq_len, torch.int32, "seq_len"), int(pad_token),
                   ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
                   ops.current_stream())
@@ -182,9 +217,10 @@ class CaptionEngine:
                "parents": torch.empty(shape, dtype=torch.int32, device=self.device),
                "scores": torch.empty(shape, dtype=torch.float32, device=self.device),
                "log_probs": torch.empty(shape, dtype=torch.float32, device=self.device)}
-        _lib.call("icap_engine_trace", self._handle, out["ids"].data_ptr(),
-                  out["parents"].data_ptr(), out["scores"].data_ptr(),
-                  out["log_probs"].data_ptr(), ops.current_stream())
+        with torch.cuda.device(self.device):
+            _lib.call("icap_engine_trace", self._handle, out["ids"].data_ptr(),
+                      out["parents"].data_ptr(), out["scores"].data_ptr(),
+                      out["log_probs"].data_ptr(), self._stream())
         return out
 
     @property
@@ -266,8 +302,13 @@ def sequence_beam_search(encoder, decoder, img, beam_width, max_len, start_id, e
     `predict_image_caption_sequence` (recurrent_example.py:477-562).
 
     img [B,L,F] -> int32 tokens [B,T] (and best-beam scores [B] if asked).  The engine
-    (workspace + weight pointers) is cached per (modules, shapes, constants)."""
+    (workspace + weight pointers) is cached per (modules, shapes, constants, weight storage);
+    weight values changed in place between two calls (an optimizer step, `kernel.copy_()`) are
+    noticed through the tensors' version counters and the derived buffers recomputed."""
     B, L, F = img.shape
+    if hasattr(encoder, "_is_relu") and not encoder._is_relu():
+        raise NotImplementedError("sequence_beam_search: the fused engine's encoder is Dense + ReLU; "
+                                  "run another activation through the module-level loop")
     if not encoder.fc.built:
         encoder.fc.build(F, img.device)
     decoder._build(encoder.fc.units, img.device)

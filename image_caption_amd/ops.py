@@ -5,25 +5,63 @@ tensors (ROCm device, dtype, contiguity, shape) and hands raw device pointers pl
 the current HIP stream to the C ABI."""
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, TILE_REFERENCE, TILE_REPEAT  # noqa: F401
 
 
+# Operands of one call must share a device, and the call runs on that device's current stream
+# with that device current - also in a process that drives several GPUs while another device
+# is the current one.  _chk notes the device of every tensor it checks; current_stream(),
+# always the last argument of a call, resolves them.
+_tls = threading.local()
+
+
+def _pending():
+    if not hasattr(_tls, "devs"):
+        _tls.devs = set()
+    return _tls.devs
+
+
 def current_stream():
-    return torch.cuda.current_stream().cuda_stream
+    devs = _pending()
+    try:
+        if len(devs) > 1:
+            raise ValueError("operands live on different devices: %s" % sorted(map(str, devs)))
+        dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
+    finally:
+        devs.clear()
+    _tls.dev = dev
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _call(name, *args):
+    """_lib.call with the operands' device current (set by current_stream() just before)."""
+    dev = getattr(_tls, "dev", None)
+    _tls.dev = None
+    if dev is None or dev.index == torch.cuda.current_device():
+        return _lib.call(name, *args)
+    with torch.cuda.device(dev):
+        return _lib.call(name, *args)
 
 
 def _chk(t, dtype, name):
-    if not isinstance(t, torch.Tensor):
-        raise TypeError("%s must be a torch.Tensor" % name)
-    if not t.is_cuda:
-        raise ValueError("%s must live on the GPU (got device %s)" % (name, t.device))
-    if t.dtype != dtype:
-        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
-        raise ValueError("%s must be contiguous" % name)
+    try:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor" % name)
+        if not t.is_cuda:
+            raise ValueError("%s must live on the GPU (got device %s)" % (name, t.device))
+        if t.dtype != dtype:
+            raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+    except Exception:
+        _pending().clear()
+        raise
+    _pending().add(t.device)
     return t.data_ptr()
 
 
@@ -43,7 +81,7 @@ def dense(x, kernel, bias=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=f32, device=x.device)
     if M:
-        _lib.call("icap_dense_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
+        _call("icap_dense_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
                   _opt(bias, f32, "bias"), _chk(out, f32, "out"), M, K, N, act, current_stream())
     return out
 
@@ -51,7 +89,7 @@ def dense(x, kernel, bias=None, act=ACT_NONE, out=None):
 def pool_features(features, mask=None):
     G, L, D = features.shape
     out = torch.empty(G, D, dtype=f32, device=features.device)
-    _lib.call("icap_pool_features_f32", _chk(features, f32, "features"), _opt(mask, f32, "mask"),
+    _call("icap_pool_features_f32", _chk(features, f32, "features"), _opt(mask, f32, "mask"),
               _chk(out, f32, "out"), G, L, D, current_stream())
     return out
 
@@ -59,7 +97,7 @@ def pool_features(features, mask=None):
 def expand_rows(src, W, scale=1.0, tile_mode=TILE_REFERENCE):
     B, H = src.shape
     out = torch.empty(B * W, H, dtype=f32, device=src.device)
-    _lib.call("icap_expand_rows_f32", _chk(src, f32, "src"), _chk(out, f32, "out"), B, W, H,
+    _call("icap_expand_rows_f32", _chk(src, f32, "src"), _chk(out, f32, "out"), B, W, H,
               float(scale), tile_mode, current_stream())
     return out
 
@@ -69,7 +107,7 @@ def embedding(table, ids):
     ids = ids.reshape(-1)
     N = ids.numel()
     out = torch.empty(N, E, dtype=f32, device=table.device)
-    _lib.call("icap_embedding_f32", _chk(table, f32, "table"), _chk(ids, i32, "ids"),
+    _call("icap_embedding_f32", _chk(table, f32, "table"), _chk(ids, i32, "ids"),
               _chk(out, f32, "out"), N, V, E, current_stream())
     return out
 
@@ -87,7 +125,7 @@ def attention(pf, features, q, v, bv, score_bias=None, gate_state=None, gate_w=N
     H = gate_state.shape[1] if gate_state is not None else 0
     ctx = torch.empty(N, D, dtype=f32, device=pf.device)
     weights = torch.empty(N, L, dtype=f32, device=pf.device) if want_weights else None
-    _lib.call("icap_attention_f32", _chk(pf, f32, "pf"), _chk(features, f32, "features"),
+    _call("icap_attention_f32", _chk(pf, f32, "pf"), _chk(features, f32, "features"),
               _chk(q, f32, "q"), _chk(v, f32, "v"), float(bv), _opt(score_bias, f32, "score_bias"),
               _opt(gate_state, f32, "gate_state"), _opt(gate_w, f32, "gate_w"), float(gate_b),
               _chk(ctx, f32, "ctx"), _opt(weights, f32, "weights"), G, rows_per_group,
@@ -114,7 +152,7 @@ def lstm_step(ctx, h, c, kernel, recurrent_kernel, bias, emb=None, table=None, i
         raise ValueError("lstm_step: kernel shapes do not match [C+E,4H] / [H,4H]")
     h_out = torch.empty_like(h)
     c_out = torch.empty_like(c)
-    _lib.call("icap_lstm_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
+    _call("icap_lstm_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
               _opt(table, f32, "table"), _opt(ids, i32, "ids"), _opt(emb_proj, f32, "emb_proj"),
               _chk(h, f32, "h"),
               _chk(c, f32, "c"), _chk(kernel, f32, "kernel"),
@@ -135,7 +173,7 @@ def gru_pack(kernel, recurrent_kernel, bias):
     k4 = torch.empty(CE, 4 * H, dtype=f32, device=kernel.device)
     r4 = torch.empty(H, 4 * H, dtype=f32, device=kernel.device)
     b4 = torch.empty(4 * H, dtype=f32, device=kernel.device)
-    _lib.call("icap_gru_pack_f32", _chk(kernel, f32, "kernel"),
+    _call("icap_gru_pack_f32", _chk(kernel, f32, "kernel"),
               _chk(recurrent_kernel, f32, "recurrent_kernel"), _chk(bias, f32, "bias"),
               k4.data_ptr(), r4.data_ptr(), b4.data_ptr(), CE, H, current_stream())
     return k4, r4, b4
@@ -158,7 +196,7 @@ def gru_step(ctx, h, kernel4, recurrent4, bias4, emb=None, table=None, ids=None,
     if kernel4.shape != (Cdim + E, 4 * H) or recurrent4.shape != (H, 4 * H):
         raise ValueError("gru_step: packed kernel shapes do not match [C+E,4H] / [H,4H]")
     h_out = torch.empty_like(h)
-    _lib.call("icap_gru_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
+    _call("icap_gru_step_f32", _chk(ctx, f32, "ctx"), _opt(emb, f32, "emb"),
               _opt(table, f32, "table"), _opt(ids, i32, "ids"), _opt(emb_proj, f32, "emb_proj"),
               _chk(h, f32, "h"), _chk(kernel4, f32, "kernel4"), _chk(recurrent4, f32, "recurrent4"),
               _chk(bias4, f32, "bias4"), _chk(h_out, f32, "h_out"), N, Cdim, E, H, V,
@@ -172,7 +210,7 @@ def logit_masks(logits, start_token=-1, row_len=None, step_plus_1=0, eos_token=-
     where step_plus_1 == row_len[n] and on all but pad_token where step_plus_1 > row_len[n]."""
     V = logits.shape[-1]
     N = logits.numel() // V
-    _lib.call("icap_logit_masks_f32", _chk(logits, f32, "logits"), N, V, int(start_token),
+    _call("icap_logit_masks_f32", _chk(logits, f32, "logits"), N, V, int(start_token),
               _opt(row_len, i32, "row_len"), int(step_plus_1), int(eos_token), int(pad_token),
               current_stream())
     return logits
@@ -183,7 +221,7 @@ def logit_masks(logits, start_token=-1, row_len=None, step_plus_1=0, eos_token=-
 def position_table(length, hidden, device):
     """[length, hidden] sinusoid position encoding (RelativePositionEmbedding)."""
     t = torch.empty(length, hidden, dtype=f32, device=device)
-    _lib.call("icap_position_table_f32", t.data_ptr(), int(length), int(hidden), current_stream())
+    _call("icap_position_table_f32", t.data_ptr(), int(length), int(hidden), current_stream())
     return t
 
 
@@ -192,7 +230,7 @@ def embed_pos(table, ids, pos_row):
     V, D = table.shape
     N = ids.numel()
     x = torch.empty(N, D, dtype=f32, device=table.device)
-    _lib.call("icap_embed_pos_f32", _chk(table, f32, "table"), _chk(ids.reshape(-1), i32, "ids"),
+    _call("icap_embed_pos_f32", _chk(table, f32, "table"), _chk(ids.reshape(-1), i32, "ids"),
               _chk(pos_row, f32, "pos_row"), x.data_ptr(), N, V, D, current_stream())
     return x
 
@@ -202,7 +240,7 @@ def add_(x, o):
     n, period = x.numel(), o.numel()
     if n % period:
         raise ValueError("add_: the addend does not tile the tensor")
-    _lib.call("icap_add_f32", _chk(x, f32, "x"), _chk(o, f32, "o"), n, period, current_stream())
+    _call("icap_add_f32", _chk(x, f32, "x"), _chk(o, f32, "o"), n, period, current_stream())
     return x
 
 
@@ -211,7 +249,7 @@ def residual_layernorm(x, o, gamma, beta, eps=1e-6):
     D = x.shape[-1]
     N = x.numel() // D
     y = torch.empty_like(x)
-    _lib.call("icap_residual_layernorm_f32", _chk(x, f32, "x"), _opt(o, f32, "o"),
+    _call("icap_residual_layernorm_f32", _chk(x, f32, "x"), _opt(o, f32, "o"),
               _chk(gamma, f32, "gamma"), _chk(beta, f32, "beta"), y.data_ptr(), N, D, float(eps),
               current_stream())
     return y
@@ -222,7 +260,7 @@ def mha_self_step(q, kv_cache, heads, key_dim, pos, mask_mode=0):
     written) -> combined values [N, heads*key_dim] of the newest position."""
     N = q.shape[0]
     out = torch.empty_like(q)
-    _lib.call("icap_mha_self_step_f32", _chk(q, f32, "q"), _chk(kv_cache, f32, "kv_cache"),
+    _call("icap_mha_self_step_f32", _chk(q, f32, "q"), _chk(kv_cache, f32, "kv_cache"),
               out.data_ptr(), N, int(heads), int(key_dim), int(pos), int(mask_mode), current_stream())
     return out
 
@@ -239,7 +277,7 @@ def mha_cross_step(q, kv, G, rows_per_group, row_stride_g, row_stride_k, heads, 
             per_group = 1
         elif tuple(mask.shape) != (rows_per_group, L):
             raise ValueError("mha_cross_step: mask must be [G,R,L] or [R,L]")
-    _lib.call("icap_mha_cross_step_f32", _chk(q, f32, "q"), _chk(kv, f32, "kv"), out.data_ptr(),
+    _call("icap_mha_cross_step_f32", _chk(q, f32, "q"), _chk(kv, f32, "kv"), out.data_ptr(),
               int(G), int(rows_per_group), int(row_stride_g), int(row_stride_k), int(L), int(heads),
               int(key_dim), _opt(mask, f32, "mask"), per_group, current_stream())
     return out
@@ -273,7 +311,7 @@ def beam_step(logits, log_probs, finished, lengths, time, eos_token, length_pena
     nfin = torch.empty(B, W, dtype=u8, device=dev)
     nlen = torch.empty(B, W, dtype=i32, device=dev)
     ws = _beam_workspace(B, R, dev)
-    _lib.call("icap_beam_step_rows_f32", _chk(logits, f32, "logits"),
+    _call("icap_beam_step_rows_f32", _chk(logits, f32, "logits"),
               _chk(log_probs, f32, "log_probs"), _chk(finished, u8, "finished"),
               _chk(lengths, i32, "lengths"), int(time), int(start_offset), int(eos_token),
               float(length_penalty_weight), 1 if input_is_log_prob else 0, scores.data_ptr(),
@@ -291,7 +329,7 @@ def sample_categorical(logits, u, step=0, row_len=None, start_token=-1, eos_toke
     N, V = logits.shape
     if out is None:
         out = torch.empty(N, dtype=i32, device=logits.device)
-    _lib.call("icap_sample_categorical_f32", _chk(logits, f32, "logits"), _chk(u, f32, "u"),
+    _call("icap_sample_categorical_f32", _chk(logits, f32, "logits"), _chk(u, f32, "u"),
               _opt(row_len, i32, "row_len"), int(step), int(start_token), int(eos_token),
               int(pad_token), _chk(out, i32, "out"), N, V, current_stream())
     return out
@@ -304,7 +342,7 @@ def backtrack(ids, parents, last_scores, last_finished):
     tokens = torch.empty(B, T, dtype=i32, device=dev)
     best = torch.empty(B, dtype=i32, device=dev)
     best_s = torch.empty(B, dtype=f32, device=dev)
-    _lib.call("icap_backtrack", _chk(ids, i32, "ids"), _chk(parents, i32, "parents"),
+    _call("icap_backtrack", _chk(ids, i32, "ids"), _chk(parents, i32, "parents"),
               _chk(last_scores, f32, "last_scores"), _chk(last_finished, u8, "last_finished"),
               tokens.data_ptr(), best.data_ptr(), best_s.data_ptr(), T, B, W, current_stream())
     return tokens, best, best_s
@@ -316,7 +354,7 @@ def beam_scores(logits, log_probs, finished, lengths, eos_token, length_penalty_
     B, W, V = logits.shape
     scores = torch.empty(B, W, V, dtype=f32, device=logits.device)
     totals = torch.empty(B, W, V, dtype=f32, device=logits.device)
-    _lib.call("icap_beam_scores_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
+    _call("icap_beam_scores_f32", _chk(logits, f32, "logits"), _chk(log_probs, f32, "log_probs"),
               _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(eos_token),
               float(length_penalty_weight), 1 if input_is_log_prob else 0, scores.data_ptr(),
               totals.data_ptr(), B, W, V, current_stream())
@@ -334,7 +372,7 @@ def beam_gather(totals, finished, lengths, word_indices, eos_token):
     nlp = torch.empty(B, K, dtype=f32, device=dev)
     nfin = torch.empty(B, K, dtype=u8, device=dev)
     nlen = torch.empty(B, K, dtype=i32, device=dev)
-    _lib.call("icap_beam_gather_f32", _chk(totals, f32, "totals"), _chk(finished, u8, "finished"),
+    _call("icap_beam_gather_f32", _chk(totals, f32, "totals"), _chk(finished, u8, "finished"),
               _chk(lengths, i32, "lengths"), _chk(word_indices, i32, "word_indices"),
               int(eos_token), ids.data_ptr(), parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(),
               nlen.data_ptr(), B, W, V, K, current_stream())
@@ -347,7 +385,7 @@ def mask_probs(probs, eos_token, finished):
     N = probs.numel() // V
     out = torch.empty_like(probs)
     if N:
-        _lib.call("icap_mask_probs_f32", _chk(probs, f32, "probs"), _chk(finished, u8, "finished"),
+        _call("icap_mask_probs_f32", _chk(probs, f32, "probs"), _chk(finished, u8, "finished"),
                   out.data_ptr(), int(eos_token), N, V, current_stream())
     return out
 
@@ -357,7 +395,7 @@ def hyp_score(log_probs, lengths, length_penalty_weight):
     the penalty itself."""
     out = torch.empty(lengths.shape, dtype=f32, device=lengths.device)
     if lengths.numel():
-        _lib.call("icap_hyp_score_f32", _opt(log_probs, f32, "log_probs"),
+        _call("icap_hyp_score_f32", _opt(log_probs, f32, "log_probs"),
                   _chk(lengths, i32, "sequence_lengths"), float(length_penalty_weight),
                   out.data_ptr(), lengths.numel(), current_stream())
     return out
@@ -369,7 +407,7 @@ def batch_gather(a, idx):
     Y = idx.shape[-1]
     out = torch.empty(B, Y, dtype=f32, device=a.device)
     if B and Y:
-        _lib.call("icap_batch_gather_f32", _chk(a, f32, "a"), _chk(idx, i32, "b"), out.data_ptr(),
+        _call("icap_batch_gather_f32", _chk(a, f32, "a"), _chk(idx, i32, "b"), out.data_ptr(),
                   B, X, Y, current_stream())
     return out
 
@@ -389,7 +427,7 @@ class PackedWeight:
         K_src, N = kernel.shape
         if N != self.N:
             raise ValueError("PackedWeight.fill: kernel has %d columns, expected %d" % (N, self.N))
-        _lib.call("icap_pack_weight_bf16", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
+        _call("icap_pack_weight_bf16", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
                   K_src, N, int(k_offset), self.K, self.gate_units, current_stream())
         return self
 
@@ -406,7 +444,7 @@ def dense_bf16(x, packed, bias=None, act=ACT_NONE):
     M = x.numel() // packed.K
     out = torch.empty(*x.shape[:-1], packed.N, dtype=f32, device=x.device)
     if M:
-        _lib.call("icap_dense_bf16", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+        _call("icap_dense_bf16", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
                   out.data_ptr(), M, packed.K, packed.N, act, current_stream())
     return out
 
@@ -421,7 +459,7 @@ def lstm_step_bf16(ctx, h, c, packed, bias, emb_proj=None, ids=None):
     h_out = torch.empty_like(h)
     c_out = torch.empty_like(c)
     V = emb_proj.shape[0] if emb_proj is not None else 0
-    _lib.call("icap_lstm_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
+    _call("icap_lstm_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
               packed.buf.data_ptr(), _opt(bias, f32, "bias"), _opt(emb_proj, f32, "emb_proj"),
               _opt(ids, i32, "ids"), h_out.data_ptr(), c_out.data_ptr(), N, C, H, V, current_stream())
     return h_out, c_out
@@ -437,7 +475,7 @@ def gru_step_bf16(ctx, h, packed, bias4, emb_proj=None, ids=None):
         raise ValueError("gru_step_bf16: packed weight does not match C=%d H=%d" % (C, H))
     h_out = torch.empty_like(h)
     V = emb_proj.shape[0] if emb_proj is not None else 0
-    _lib.call("icap_gru_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), packed.buf.data_ptr(),
+    _call("icap_gru_step_bf16", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), packed.buf.data_ptr(),
               _opt(bias4, f32, "bias4"), _opt(emb_proj, f32, "emb_proj"), _opt(ids, i32, "ids"),
               h_out.data_ptr(), N, C, H, V, current_stream())
     return h_out
@@ -456,7 +494,7 @@ def dense_topk(x, kernel, bias, eos_token, top_k):
         raise ValueError("dense_topk: top_k must be 1, 3 or 5")
     rec = torch.empty(M, ht, rl, dtype=f32, device=x.device)
     eos_logit = torch.zeros(M, dtype=f32, device=x.device)
-    _lib.call("icap_dense_topk_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
+    _call("icap_dense_topk_f32", _chk(x, f32, "x"), _chk(kernel, f32, "kernel"),
               _opt(bias, f32, "bias"), M, K, N, int(eos_token), int(top_k), rec.data_ptr(),
               eos_logit.data_ptr(), current_stream())
     return rec, eos_logit
@@ -477,7 +515,7 @@ def beam_step_from_records(rec, eos_logit, log_probs, finished, lengths, time, e
     nlp = torch.empty(B, W, dtype=f32, device=dev)
     nfin = torch.empty(B, W, dtype=u8, device=dev)
     nlen = torch.empty(B, W, dtype=i32, device=dev)
-    _lib.call("icap_beam_step_from_records_f32", _chk(rec, f32, "records"),
+    _call("icap_beam_step_from_records_f32", _chk(rec, f32, "records"),
               _chk(eos_logit, f32, "eos_logit"), ht, top_k, _chk(log_probs, f32, "log_probs"),
               _chk(finished, u8, "finished"), _chk(lengths, i32, "lengths"), int(time),
               int(eos_token), float(length_penalty_weight), scores.data_ptr(), ids.data_ptr(),
@@ -501,7 +539,7 @@ class PackedSplitWeight:
         K_src, N = kernel.shape
         if N != self.N:
             raise ValueError("PackedSplitWeight.fill: kernel has %d columns, expected %d" % (N, self.N))
-        _lib.call("icap_pack_weight_split", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
+        _call("icap_pack_weight_split", _chk(kernel, f32, "kernel"), self.buf.data_ptr(),
                   K_src, N, int(k_offset), self.K, self.gate_units, current_stream())
         return self
 
@@ -517,7 +555,7 @@ def dense_split(x, packed, bias=None, act=ACT_NONE):
     M = x.numel() // packed.K
     out = torch.empty(*x.shape[:-1], packed.N, dtype=f32, device=x.device)
     if M:
-        _lib.call("icap_dense_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+        _call("icap_dense_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
                   out.data_ptr(), M, packed.K, packed.N, act, current_stream())
     return out
 
@@ -531,7 +569,7 @@ def dense_topk_split(x, packed, bias, eos_token, top_k):
         raise ValueError("dense_topk_split: top_k must be 1, 3 or 5")
     rec = torch.empty(M, ht, rl, dtype=f32, device=x.device)
     eos_logit = torch.zeros(M, dtype=f32, device=x.device)
-    _lib.call("icap_dense_topk_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
+    _call("icap_dense_topk_split", _chk(x, f32, "x"), packed.buf.data_ptr(), _opt(bias, f32, "bias"),
               M, packed.K, packed.N, int(eos_token), int(top_k), rec.data_ptr(), eos_logit.data_ptr(),
               current_stream())
     return rec, eos_logit
@@ -547,7 +585,7 @@ def lstm_step_split(ctx, h, c, packed, bias, emb_proj=None, ids=None):
     h_out = torch.empty_like(h)
     c_out = torch.empty_like(c)
     V = emb_proj.shape[0] if emb_proj is not None else 0
-    _lib.call("icap_lstm_step_split", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
+    _call("icap_lstm_step_split", _chk(ctx, f32, "ctx"), _chk(h, f32, "h"), _chk(c, f32, "c"),
               packed.buf.data_ptr(), _opt(bias, f32, "bias"), _opt(emb_proj, f32, "emb_proj"),
               _opt(ids, i32, "ids"), h_out.data_ptr(), c_out.data_ptr(), N, C, H, V, current_stream())
     return h_out, c_out

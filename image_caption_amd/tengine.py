@@ -148,7 +148,10 @@ class TransformerEngine:
             out = torch.empty(c.B, c.T, dtype=torch.int32, device=self.device)
         if scores is None:
             scores = torch.empty(c.B, dtype=torch.float32, device=self.device)
-        _lib.call("icap_tdecode", self._handle, ops._chk(img, torch.float32, "img"),
+        for name, t in (("img", img), ("out", out), ("scores", scores)):
+            if t.is_cuda and t.device != self.device:
+                raise ValueError("%s lives on %s, the engine on %s" % (name, t.device, self.device))
+        ops._call("icap_tdecode", self._handle, ops._chk(img, torch.float32, "img"),
                   ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
                   ops.current_stream())
         return out, scores
@@ -160,15 +163,19 @@ class TransformerEngine:
                "parents": torch.empty(shape, dtype=torch.int32, device=self.device),
                "scores": torch.empty(shape, dtype=torch.float32, device=self.device),
                "log_probs": torch.empty(shape, dtype=torch.float32, device=self.device)}
-        _lib.call("icap_tengine_trace", self._handle, out["ids"].data_ptr(), out["parents"].data_ptr(),
-                  out["scores"].data_ptr(), out["log_probs"].data_ptr(), ops.current_stream())
+        with torch.cuda.device(self.device):
+            _lib.call("icap_tengine_trace", self._handle, out["ids"].data_ptr(),
+                      out["parents"].data_ptr(), out["scores"].data_ptr(), out["log_probs"].data_ptr(),
+                      torch.cuda.current_stream(self.device).cuda_stream)
         return out
 
     def last_output(self):
         """The stack's normalised output of the newest position at the last step [N, hidden]."""
         c = self.config
         t = torch.empty(c.N, c.hidden, dtype=torch.float32, device=self.device)
-        _lib.call("icap_tengine_last_output", self._handle, t.data_ptr(), ops.current_stream())
+        with torch.cuda.device(self.device):
+            _lib.call("icap_tengine_last_output", self._handle, t.data_ptr(),
+                      torch.cuda.current_stream(self.device).cuda_stream)
         return t
 
     def set_timing(self, kernels):

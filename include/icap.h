@@ -13,7 +13,9 @@
  *     recurrent_kernel [H,4H] / bias [4H] with gate order i,f,g,o.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls only
  *     enqueue work; they never synchronise the stream and never allocate, except
- *     icap_engine_create / icap_engine_destroy.
+ *     icap_engine_create / _destroy / _refresh_weights (and their icap_tengine_ twins),
+ *     icap_engine_set_timing (creates the event pool) and icap_engine_kernel_times (waits
+ *     for the recorded events).
  *   - return value: ICAP_OK (0) or a negative ICAP_ERR_* code; the message is kept
  *     per host thread and read with icap_last_error().  Nothing throws across the ABI.
  *   - bool tensors are one byte per element (0/1), ids and lengths are int32.
@@ -361,9 +363,12 @@ typedef struct icap_engine icap_engine;
 int icap_engine_create(const icap_config* config, const icap_weights* weights,
                        icap_engine** out);
 int icap_engine_destroy(icap_engine* engine);
-/* Recomputes what the engine derives from the weights (the [V,4H] token part of the LSTM
- * gates).  icap_engine_create does this once on the null stream and waits for it; call
- * again after changing the embedding or the LSTM kernel in place. */
+/* Recomputes everything the engine derives from the weights: the [V,4H] token part of the
+ * LSTM gates, the GRU re-layout, the packed bf16 / split copies, and the two scalar biases
+ * (att_v_bias, fc3_bias) that travel to the kernels by value.  icap_engine_create does this
+ * once on the null stream; call it again after changing ANY weight value in place.  It
+ * enqueues on `stream` behind the caller's writes and waits for the stream (the scalars are
+ * read back to the host): the one engine call besides create / destroy that synchronises. */
 int icap_engine_refresh_weights(icap_engine* engine, icap_stream_t stream);
 /* Bytes of device workspace the engine holds. */
 size_t icap_engine_workspace_bytes(const icap_engine* engine);
@@ -408,7 +413,10 @@ int icap_engine_trace(const icap_engine* engine, int32_t* ids, int32_t* parents,
  * class whose bit is set in `class_mask` (bit ICAP_K_*) are bracketed by events;
  * 0 disables timing.  icap_engine_kernel_times synchronises those events and returns,
  * per kernel class, the summed duration in milliseconds and the launch count since
- * the mask was last set. */
+ * the mask was last set.  icap_engine_set_timing creates the event pool (enough for
+ * ICAP_TIMING_POOL_DECODES bracketed decodes between two reads; launches beyond it go
+ * unbracketed), so that icap_decode itself never creates an event. */
+#define ICAP_TIMING_POOL_DECODES 64
 #define ICAP_K_ENCODE 0
 #define ICAP_K_FEAT_PROJ 1
 #define ICAP_K_INIT_STATE 2
@@ -580,6 +588,9 @@ int icap_tengine_last_output(const icap_tengine* engine, float* out, icap_stream
 #define ICAP_TK_BEAM 8
 #define ICAP_TK_BACKTRACK 9
 #define ICAP_TK_COUNT 10
+/* As icap_engine_set_timing: creates the event pool (ICAP_TTIMING_POOL_DECODES bracketed
+ * decodes between two reads), so that icap_tdecode creates no event. */
+#define ICAP_TTIMING_POOL_DECODES 24
 int icap_tengine_set_timing(icap_tengine* engine, unsigned class_mask);
 int icap_tengine_kernel_times(icap_tengine* engine, float* ms /*[ICAP_TK_COUNT]*/,
                               int32_t* launches /*[ICAP_TK_COUNT]*/);

@@ -417,7 +417,7 @@ def tile_features(features, beam_width, tile_mode):
 def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id,
                                    length_penalty_weight=1.0, tile_mode="reference",
                                    reset_state_from_feat=1, return_trace=False,
-                                   hoist_w1=False, cell="lstm"):
+                                   hoist_w1=False, cell="lstm", choose_successors_fn=None):
     """`predict_image_caption_sequence` (`recurrent_example.py:477-562`).
 
     encoder -> tile -> reset_state -> T x (decoder step, beam step) -> back-track.
@@ -428,6 +428,9 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     `cell="gru"` runs the same loop over the GRU sibling decoder
     (`decoder/recurrent_decoder.py`; no driver in the reference constructs it, the loop is
     the LSTM one with the decoder swapped).
+    `choose_successors_fn` replaces `choose_top_k` in the beam-search config (the driver
+    passes `choose_top_k`, `:505-509`; the parity tests pass a chooser that follows another
+    implementation through proven near-ties).
     Returns int32 tokens [B,T] (and the per-step trace if asked)."""
     if cell not in ("lstm", "gru"):
         raise ValueError("cell must be 'lstm' or 'gru'")
@@ -441,7 +444,8 @@ def predict_image_caption_sequence(p, img, beam_width, max_len, start_id, eos_id
     hidden = reset_fn(p, B * W, features, reset_state_from_feat)
     V = p["fc2_kernel"].shape[1]
     state = create_initial_beam_state_batch(B, W, dtype=img.dtype)
-    config = BeamSearchConfig(W, V, eos_id, length_penalty_weight, choose_top_k)
+    config = BeamSearchConfig(W, V, eos_id, length_penalty_weight,
+                              choose_successors_fn or choose_top_k)
     seq = []
     trace = []
     w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"]) if hoist_w1 else None
@@ -614,6 +618,25 @@ def make_params(seed, F, D, E, H, V, U=None, C=None):
     p["fc1_bias"] = np.zeros(H, np.float32)
     p["fc2_kernel"] = _glorot(rng, H, V)
     p["fc2_bias"] = np.zeros(V, np.float32)
+    return p
+
+
+def make_peaked_params(seed, F, D, E, H, V, U=None, C=None, eos_id=4):
+    """`make_params` rescaled towards what trained weights look like, for parity tests whose
+    token decisions must not hinge on fp32 summation order: Keras-default weights give
+    near-flat word distributions (logit spread 0.02: half of all top-k decisions have a
+    relative score margin below 1e-5 and every image decodes to the same few tokens).  Here the
+    embedding (x20), the LSTM kernels (x4, x2), the attention score vector (x8), the initial
+    state projections (x2) and the vocabulary projection (x64) are scaled up and the end token
+    gets a bias of 9: logit spread about 5, captions that differ per image, and the end token
+    reached at every length between 1 and T for about half of the images."""
+    p = make_params(seed, F, D, E, H, V, U, C)
+    f = np.float32
+    for name, gain in (("embedding", 20), ("lstm_kernel", 4), ("lstm_recurrent_kernel", 2),
+                       ("fc2_kernel", 64), ("att_V_kernel", 8), ("init0_kernel", 2),
+                       ("init1_kernel", 2)):
+        p[name] = (p[name] * f(gain)).astype(np.float32)
+    p["fc2_bias"][eos_id] = 9.0
     return p
 
 

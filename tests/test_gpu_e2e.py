@@ -1,16 +1,19 @@
 """Decoder step and whole-sequence decode vs the oracle.
 
-Token ids must be identical to the fp32 oracle.  Both sides are fp32 with different
-summation orders, so a top-k decision whose two candidates are closer than fp32
-noise can legitimately flip; any image whose tokens differ is therefore checked
-against the oracle's own score margins and must be a proven near-tie (relative
-margin below 2e-5), otherwise the test fails.  Log-probs: 1e-5 relative."""
+Token ids and every per-step beam record must be identical to the fp32 oracle.  Both sides
+are fp32 with different summation orders, so a top-k decision between candidates closer than
+fp32 noise can legitimately come out differently: the oracle runs in lockstep with the
+engine's records and adopts an engine pick only where it is a proven near-tie at its rank
+(oracle score within 2e-6 relative of the oracle's own pick), so every later step stays
+checked; anything else fails (tests/helpers.check_decode_following).  Log-probs and scores:
+1e-5 relative, every image, every step.  On weights with peaked word distributions
+(`make_peaked_params`) no adoption at all is tolerated."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import caption_oracle as co
-from tests.helpers import assert_close, dev, np_of, prefer_fused, to_dev
+from tests.helpers import assert_close, check_decode_following, dev, np_of, prefer_fused, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -96,35 +99,20 @@ def test_decoder_step_with_callable_embedding_and_bias():
     assert isinstance(dec.copy(), LstmDecoder)
 
 
-def _first_divergence(trace_o, tr_g, b):
-    for t, st in enumerate(trace_o):
-        if (np_of(tr_g["ids"][t, b]) != st["out"].predicted_ids[b]).any() or \
-                (np_of(tr_g["parents"][t, b]) != st["out"].beam_parent_ids[b]).any():
-            return t
-    return None
+def _params(dims, seed, bias_seed=None, peaked=False):
+    p = (co.make_peaked_params if peaked else co.make_params)(seed, **dims)
+    return co.perturb_biases(p, bias_seed) if bias_seed is not None else p
 
 
-def _oracle_margin(trace_o, t, b, W, V, eos, lpw):
-    """Smallest relative gap around the top-W decision of image b at step t in the oracle."""
-    st = trace_o[t]
-    prev = trace_o[t - 1]["state"] if t > 0 else co.create_initial_beam_state_batch(
-        st["logits"].shape[0], W)
-    one = co.BeamSearchState(prev.log_probs[b:b + 1], prev.finished[b:b + 1], prev.lengths[b:b + 1])
-    cfg = co.BeamSearchConfig(W, V, eos, lpw, lambda s, k: co.choose_top_k(s, min(k + 1, s.shape[-1])))
-    out, _ = co.beam_search_step_batch(t, st["logits"][b:b + 1], one, cfg)
-    s = out.scores[0].astype(np.float64)
-    gaps = np.abs(np.diff(s)) / np.maximum(np.abs(s[:-1]), 1e-30)
-    return float(gaps.min())
-
-
-def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0, setup=None):
+def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0, setup=None,
+                    peaked=False, img=None):
+    """Engine decode against the oracle following it through proven near-ties
+    (tests/helpers.check_decode_following): every step of every image is checked.  Returns
+    (number of images that needed a near-tie adoption, the adopted ties)."""
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
-    p = co.make_params(seed, **dims)
-    if bias_seed is not None:
-        p = co.perturb_biases(p, bias_seed)
-    img = co.make_images(seed + 50, B, L, dims["F"])
-    tok_o, trace_o = co.predict_image_caption_sequence(p, img, W, T, 3, 4, lpw, tile_mode,
-                                                       return_trace=True)
+    p = _params(dims, seed, bias_seed, peaked)
+    if img is None:
+        img = co.make_images(seed + 50, B, L, dims["F"])
     cfg = CaptionConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], E=dims["E"], H=dims["H"],
                         U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
                         length_penalty_weight=lpw, tile_mode=tile_mode, **cfg_kw)
@@ -133,33 +121,11 @@ def _compare_decode(cfg_kw, dims, seed, B, L, T, W, tile_mode, bias_seed=None, l
     if setup is not None:
         setup(eng)
     tok_g, _ = eng.decode(to_dev(img))
-    tr_g = eng.trace()
+    tr_g = {k: np_of(v) for k, v in eng.trace().items()}
     tok_g = np_of(tok_g)
-    assert tok_g.shape == (B, T) and tok_g.dtype == np.int32
-    bad = [b for b in range(B) if (tok_g[b] != tok_o[b]).any()]
-    explained = []
-    for b in bad:
-        t = _first_divergence(trace_o, tr_g, b)
-        assert t is not None, "image %d: tokens differ but the beam records agree" % b
-        m = _oracle_margin(trace_o, t, b, W, dims["V"], 4, lpw)
-        assert m < 2e-5, "image %d diverges at step %d with oracle margin %.3e" % (b, t, m)
-        explained.append((b, t, m))
-    # log-probs of the images that agree, every step
-    good = [b for b in range(B) if b not in bad]
-    lp_o = np.stack([st["state"].log_probs for st in trace_o])[:, good]
-    sc_o = np.stack([st["out"].scores for st in trace_o])[:, good]
-    ids_o = np.stack([st["out"].predicted_ids for st in trace_o])[:, good]
-    keep = np.array([_first_divergence(trace_o, tr_g, b) is None for b in good])
-    lp_g = np_of(tr_g["log_probs"])[:, good]
-    sc_g = np_of(tr_g["scores"])[:, good]
-    np.testing.assert_array_equal(np_of(tr_g["ids"])[:, good][:, keep], ids_o[:, keep])
-    with np.errstate(over="ignore"):
-        assert_close(np.maximum(lp_g[:, keep], -1e30), np.maximum(lp_o[:, keep], -1e30), rtol=1e-5,
-                     what="log_probs")
-        assert_close(np.maximum(sc_g[:, keep], -1e30), np.maximum(sc_o[:, keep], -1e30), rtol=1e-5,
-                     what="scores")
     eng.close()
-    return len(bad), explained
+    assert tok_g.shape == (B, T) and tok_g.dtype == np.int32
+    return check_decode_following(p, img, W, T, 3, 4, lpw, tile_mode, tok_g, tr_g)
 
 
 @pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
@@ -277,8 +243,8 @@ def test_decode_edge_sizes(B, L, T, W, V):
     for tile_mode in ("reference", "repeat"):
         nbad, explained = _compare_decode({}, dims, seed=B + L + T + W, B=B, L=L, T=T, W=W,
                                           tile_mode=tile_mode, bias_seed=2)
-        # (a long decode may hit a tie of the oracle's own scores: margin of a few ulps at most)
-        assert nbad == 0 or (T >= 30 and nbad <= 1 and all(m < 1e-6 for _, _, m in explained)), explained
+        # (a long decode may hit a tie of the oracle's own scores: a few ulps at most)
+        assert nbad == 0 or (T >= 30 and nbad <= 1), explained
 
 
 def test_engine_rejects_bad_shapes_and_arguments():
@@ -312,8 +278,11 @@ def test_decode_medium_production_dims():
     dims = dict(F=2048, D=256, E=256, H=512, V=10000)
     nbad, explained = _compare_decode({}, dims, seed=0, B=16, L=64, T=20, W=3,
                                       tile_mode="reference")
-    # (ties between the identical start rows of an image's beams: margins of 1e-7 at most)
-    assert nbad <= 2 and all(m < 2e-6 for _, _, m in explained), explained
+    # (Keras-default weights: near-flat word distributions, ties of a few ulps are common)
+    assert nbad <= 5, explained
+    nbad, explained = _compare_decode({}, dims, seed=0, B=16, L=64, T=20, W=3,
+                                      tile_mode="reference", peaked=True)
+    assert nbad == 0, explained
 
 
 def test_sequence_beam_search_entry_matches_engine():
@@ -390,19 +359,29 @@ def test_fused_and_unfused_vocab_paths_agree():
 PROD = dict(F=2048, D=256, E=256, H=512, V=10000)
 
 
-def test_decode_full_size_config2_against_oracle():
+def test_decode_full_size_config2_flat_weights_tie_stress():
     """The headline configuration at full size (512 images, beam 3, 20 steps, V = 10000,
-    fp32, reference tile order) against the oracle: tokens identical except where the
-    oracle's own decision margin is below 2e-5 (each such image is checked and listed),
-    log-probs and scores of the agreeing images within 1e-5."""
+    fp32, reference tile order) on Keras-default weights.  Their word distributions are
+    nearly flat (logit spread 0.02), so half of the oracle's own top-k decisions have margins
+    below 1e-5: the tie-order stress.  Every engine pick that differs from the oracle's is
+    proven a near-tie at its rank (2e-6) and the oracle follows it, so all 512 x 20 x 3
+    records, log-probs and scores are checked (1e-5)."""
     nbad, explained = _compare_decode({}, PROD, seed=0, B=512, L=64, T=20, W=3,
                                       tile_mode="reference")
-    print("full size: %d of 512 images differ from the oracle, all explained as near ties: %s"
-          % (nbad, explained))
-    # Tied hypotheses are common in the reference tile order (beams of one image start from
-    # identical rows); they show up as margins of a few 1e-7 at most.
-    assert all(m < 2e-6 for _, _, m in explained), explained
-    assert nbad <= 51, explained          # 10 % of the batch
+    print("flat weights, full size: %d of 512 images took a near-tie adoption (%d picks, largest "
+          "gap %.2e)" % (nbad, len(explained), max([g for *_, g in explained] or [0.0])))
+    assert nbad <= 40, explained          # observed: 23
+
+
+@pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
+def test_decode_full_size_config2_peaked_weights_exact(tile_mode):
+    """The headline configuration at full size on weights with peaked word distributions
+    (logit spread about 5, captions that differ per image, the end token reached at every
+    length): the engine's tokens and all its beam records equal the free-running oracle's,
+    with ZERO near-tie adoptions, and log-probs / scores agree to 1e-5."""
+    nbad, explained = _compare_decode({}, PROD, seed=0, B=512, L=64, T=20, W=3, tile_mode=tile_mode,
+                                      peaked=True)
+    assert nbad == 0, explained
 
 
 def test_decode_full_size_is_permutation_equivariant():
@@ -454,3 +433,62 @@ def test_fused_path_is_the_default_from_one_tile_per_cu_upwards():
                                       H=PROD["H"], U=PROD["H"], V=PROD["V"], T=2), p, device=dev())
     assert big.fused_vocab
     big.close()
+
+
+def test_weights_changed_in_place_are_picked_up_by_cached_engines():
+    """An optimizer step or `kernel.copy_()` between two calls changes weight values behind
+    the engine's pointers.  What the engine derives from them (the token part of the gates,
+    the two scalar biases it hands to kernels by value) must follow: `sequence_beam_search`'s
+    cached engine notices the tensors' version counters, and an explicit
+    `refresh_weights()` serves writers that bypass torch.  Checked against the oracle on the
+    changed weights."""
+    from image_caption_amd import sequence_beam_search
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    DIMS64 = dict(F=64, D=64, E=64, H=64, V=200)       # (bf16 mode wants multiples of 64)
+    p = co.perturb_biases(co.make_peaked_params(4, **DIMS64), 5)
+    p["fc2_bias"][4] = 0.0                             # (200 words: no extra weight on the end token)
+    enc, dec = _modules(p, DIMS64)
+    B, L, W, T = 6, 5, 3, 7
+    img = co.make_images(6, B, L, DIMS64["F"])
+    tok0 = np_of(sequence_beam_search(enc, dec, to_dev(img), W, T, 3, 4))
+    np.testing.assert_array_equal(tok0, co.predict_image_caption_sequence(p, img, W, T, 3, 4))
+    # in-place updates of a matrix the engine derives from, and of both by-value scalars
+    rng = np.random.default_rng(7)
+    q = dict(p)
+    q["embedding"] = (p["embedding"] + rng.normal(0, 0.5, p["embedding"].shape)).astype(np.float32)
+    q["lstm_kernel"] = (p["lstm_kernel"] * 0.7).astype(np.float32)
+    q["fc3_bias"] = np.array([1.5], np.float32)
+    q["att_V_bias"] = np.array([-0.4], np.float32)     # (softmax is shift invariant: a no-op check)
+    q["fc2_bias"] = (p["fc2_bias"] + rng.normal(0, 1.0, p["fc2_bias"].shape)).astype(np.float32)
+    dec.embedding_layer.table.copy_(to_dev(q["embedding"]))
+    dec.lstm.kernel.copy_(to_dev(q["lstm_kernel"]))
+    dec.fc3.bias.copy_(to_dev(q["fc3_bias"]))
+    dec.attention.V.bias.copy_(to_dev(q["att_V_bias"]))
+    dec.fc2.bias.copy_(to_dev(q["fc2_bias"]))
+    tok_q = co.predict_image_caption_sequence(q, img, W, T, 3, 4)
+    assert (tok_q != tok0).any()
+    tok1 = np_of(sequence_beam_search(enc, dec, to_dev(img), W, T, 3, 4))
+    np.testing.assert_array_equal(tok1, tok_q)
+    # an engine on its own device copies (numpy in), changed through raw storage views:
+    # nothing bumps a version the engine can see, so the caller refreshes explicitly
+    for precision in ("fp32", "fp32_split", "bf16"):
+        cfg = CaptionConfig(B=B, W=W, L=L, F=DIMS64["F"], D=DIMS64["D"], E=DIMS64["E"],
+                            H=DIMS64["H"], U=DIMS64["H"], V=DIMS64["V"], T=T, precision=precision)
+        eng = CaptionEngine(cfg, p, device=dev())
+        a = np_of(eng.decode(to_dev(img))[0]).copy()
+        for name, field in (("embedding", "embedding"), ("lstm_kernel", "lstm_kernel"),
+                            ("fc3_bias", "fc3_bias"), ("fc2_bias", "fc2_bias")):
+            eng.weights[field].detach().view(-1).data.copy_(to_dev(q[name]).view(-1))
+        eng._versions = eng._weight_versions()         # as if the write had bypassed torch
+        eng.refresh_weights()
+        b = np_of(eng.decode(to_dev(img))[0])
+        if precision != "bf16":
+            np.testing.assert_array_equal(a, tok0)
+            np.testing.assert_array_equal(b, tok_q)
+        else:
+            # the packed bf16 copies were rebuilt: an engine created on the new weights agrees
+            fresh = CaptionEngine(cfg, q, device=dev())
+            np.testing.assert_array_equal(b, np_of(fresh.decode(to_dev(img))[0]))
+            fresh.close()
+            assert (a != b).any()
+        eng.close()

@@ -4,14 +4,15 @@ decoder module and the whole-sequence decode with cell="gru".
 No reference test or fixture covers this decoder (no driver in the reference constructs
 it): parity unpinned, the checker is the oracle's restatement of recurrent_decoder.py and
 of the Keras GRUCell contract.  Bars as for the LSTM path: 1e-5 relative on states and
-log-probs, identical tokens except proven fp32 near-ties."""
+log-probs; whole-sequence decodes are checked by the oracle following the engine's records
+through proven near-ties (tests/helpers.check_decode_following)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import caption_oracle as co
-from tests.helpers import assert_close, dev, np_of, prefer_fused, to_dev
-from tests.test_gpu_e2e import SMALL, _first_divergence, _oracle_margin
+from tests.helpers import assert_close, check_decode_following, dev, np_of, prefer_fused, to_dev
+from tests.test_gpu_e2e import SMALL
 
 pytestmark = pytest.mark.gpu
 
@@ -116,35 +117,21 @@ def test_gru_decoder_step_module(dims, N, L):
 
 
 def _compare_gru_decode(dims, seed, B, L, T, W, tile_mode, bias_seed=None, lpw=1.0, **cfg_kw):
+    """GRU engine decode against the oracle following it through proven near-ties: every step
+    of every image checked.  Returns (images with a near-tie adoption, the adopted ties)."""
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
     p = _gru_params(seed, dims, bias_seed)
     img = co.make_images(seed + 50, B, L, dims["F"])
-    tok_o, trace_o = co.predict_image_caption_sequence(p, img, W, T, 3, 4, lpw, tile_mode,
-                                                       return_trace=True, cell="gru")
     cfg = CaptionConfig(B=B, W=W, L=L, F=dims["F"], D=dims["D"], E=dims["E"], H=dims["H"],
                         U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4,
                         length_penalty_weight=lpw, tile_mode=tile_mode, cell="gru", **cfg_kw)
     eng = CaptionEngine(cfg, p, device=dev())
     prefer_fused(eng)
     tok_g, _ = eng.decode(to_dev(img))
-    tr_g = eng.trace()
+    tr_g = {k: np_of(v) for k, v in eng.trace().items()}
     tok_g = np_of(tok_g)
-    bad = [b for b in range(B) if (tok_g[b] != tok_o[b]).any()]
-    explained = []
-    for b in bad:
-        t = _first_divergence(trace_o, tr_g, b)
-        assert t is not None, "image %d: tokens differ but the beam records agree" % b
-        m = _oracle_margin(trace_o, t, b, W, dims["V"], 4, lpw)
-        assert m < 2e-5, "image %d diverges at step %d with oracle margin %.3e" % (b, t, m)
-        explained.append((b, t, m))
-    good = [b for b in range(B) if b not in bad]
-    keep = np.array([_first_divergence(trace_o, tr_g, b) is None for b in good], bool)
-    lp_o = np.stack([st["state"].log_probs for st in trace_o])[:, good][:, keep]
-    lp_g = np_of(tr_g["log_probs"])[:, good][:, keep]
-    with np.errstate(over="ignore"):
-        assert_close(np.maximum(lp_g, -1e30), np.maximum(lp_o, -1e30), rtol=1e-5, what="log_probs")
     eng.close()
-    return len(bad), explained
+    return check_decode_following(p, img, W, T, 3, 4, lpw, tile_mode, tok_g, tr_g, cell="gru")
 
 
 @pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
@@ -230,10 +217,10 @@ def test_gru_engine_bf16_scores_within_the_bf16_bar():
 
 def test_gru_decode_full_size_headline_shape():
     """The headline shape (512 images, beam 3, 20 steps, V = 10000, fp32, reference tile order)
-    over the GRU decoder against the oracle: tokens identical except proven fp32 near-ties,
-    log-probs of the agreeing images within 1e-5."""
+    over the GRU decoder (Keras-default weights: near-flat word distributions) against the oracle
+    following it: every differing pick a proven near-tie at its rank (2e-6), all records,
+    log-probs and scores of all images within 1e-5."""
     dims = dict(F=2048, D=256, E=256, H=512, V=10000)
     nbad, explained = _compare_gru_decode(dims, seed=0, B=512, L=64, T=20, W=3, tile_mode="reference")
-    print("GRU full size: %d of 512 images differ, all near ties: %s" % (nbad, explained))
-    assert all(m < 2e-6 for _, _, m in explained), explained
+    print("GRU full size: %d of 512 images took a near-tie adoption (%d picks)" % (nbad, len(explained)))
     assert nbad <= 51, explained

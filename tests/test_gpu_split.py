@@ -94,7 +94,7 @@ def test_topk_records_split_equal_f32_records(ops):
     r32, e32 = ops.dense_topk(to_dev(x), to_dev(w), to_dev(b), 4, 3)
     rsp, esp = ops.dense_topk_split(to_dev(x), ops.pack_weight_split(to_dev(w)), to_dev(b), 4, 3)
     r32, rsp = np_of(r32), np_of(rsp)
-    assert_close(rsp[:, :, :5], r32[:, :, :5], rtol=1e-5, what="record values")
+    assert_close(rsp[:, :, :5], r32[:, :, :5], rtol=1e-5, what="record values", allow_inf=True)  # (-inf: empty slots)
     same = rsp[:, :, 5:].view(np.int32) == r32[:, :, 5:].view(np.int32)
     assert same.mean() > 0.999                      # columns agree except for fp32-level ties
     assert_close(np_of(esp), np_of(e32), rtol=1e-5, what="eos logit")
@@ -109,14 +109,17 @@ def test_engine_split_small_against_oracle():
 
 def test_engine_split_full_size_config2_against_oracle():
     """The headline configuration in split mode against the fp32 oracle, at the fp32 bars:
-    tokens identical except at decisions whose oracle margin is a tie at fp32 resolution
-    (< 2e-6), log-probs and scores of the agreeing images within 1e-5."""
+    the oracle follows the engine's records, every differing pick a proven near-tie at its rank
+    (2e-6), log-probs and scores of all images within 1e-5; on the peaked weights no near-tie
+    adoption at all."""
     nbad, explained = _compare_decode({"precision": "fp32_split"}, PROD, seed=0, B=512, L=64, T=20,
                                       W=3, tile_mode="reference")
-    print("split mode, full size: %d of 512 images differ from the oracle, all near ties: %s"
-          % (nbad, explained))
-    assert all(m < 2e-6 for _, _, m in explained), explained
+    print("split mode, full size, flat weights: %d of 512 images took a near-tie adoption"
+          % nbad)
     assert nbad <= 51, explained
+    nbad, explained = _compare_decode({"precision": "fp32_split"}, PROD, seed=0, B=512, L=64, T=20,
+                                      W=3, tile_mode="reference", peaked=True)
+    assert nbad == 0, explained
 
 
 def test_engine_split_rejects_unaligned_dims():
