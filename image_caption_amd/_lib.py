@@ -116,6 +116,8 @@ SIGNATURES = {
     "icap_dense_topk_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "icap_beam_step_from_records_f32": ([_P, _P, _I, _I, _P, _P, _P, _I, _I, _D, _P, _P, _P, _P,
                                          _P, _P, _I, _I, _I, _P], C.c_int),
+    "icap_beam_step_from_records_wide_f32": ([_P, _P, _I, _I, _P, _P, _P, _I, _I, _D, _P, _P, _P,
+                                              _P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
     "icap_beam_scores_f32": ([_P, _P, _P, _P, _I, _D, _I, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_beam_gather_f32": ([_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "icap_mask_probs_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),

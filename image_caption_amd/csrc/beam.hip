@@ -52,6 +52,11 @@ struct BeamArgs {
   float* ws_total;   // [B*R*WL_MAX]
   int* ws_idx;       // [B*R*WL_MAX]
   Penalty pen;
+  // Device-side switch (engine only; both null otherwise): the launch does nothing unless
+  // *run_flag != 0, and the merge kernel zeroes *clear_flag (a word no workgroup of this
+  // launch tests) either way.
+  const int* run_flag = nullptr;
+  int* clear_flag = nullptr;
 };
 
 __device__ __forceinline__ bool cand_better(float sa, int ia, float sb, int ib) {
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
   const int wave = tid >> 6;
   const size_t rw = (size_t)b * R + w;
 
+  if (p.run_flag != nullptr && *p.run_flag == 0) return;
   const bool first = p.time <= 0;
   const bool scan = first ? (w == p.start_offset) : true;
   const bool stats_only = !scan && first && w == 0;  // beam 0 feeds the time-0 log-prob gather
@@ -415,6 +421,8 @@ template <int WL>
 __global__ __launch_bounds__(256) void beam_merge_kernel(BeamArgs p) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p.clear_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.clear_flag = 0;
+  if (p.run_flag != nullptr && *p.run_flag == 0) return;
   if (b >= p.B) return;
   const int W = p.W, R = p.R, V = p.V;
   const bool first = p.time <= 0;
@@ -740,6 +748,221 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
   }
 }
 
+// ---- the same step for wide beams (W up to 16) and any number of records per image ----
+// The records hold each half tile's best WL (< W) logits, so a half tile can hide candidates:
+// the kernel proves for every image that none of them matters, and raises *overflow
+// otherwise (the caller then repeats the step on full logits).  One workgroup of 1024
+// threads per image:
+//   A. wave w folds the records of beam row w into the row max and log-sum-exp;
+//   B. every thread scores the best logit of its records exactly; the W-th largest of the
+//      thread maxima is a lower bound T on the W-th best score (W different candidates reach it);
+//   C. every recorded logit whose exact score reaches T is a contender and goes to a list
+//      in LDS together with the synthetic candidates (eos, finished rows).  If the LAST
+//      stored logit of a record is a contender, logits the record does not hold could be
+//      contenders too: overflow.  A full list: overflow.
+//   D. wave 0 extracts the W winners from the list in tf.nn.top_k order.
+constexpr int WIDE_NT = 1024;
+constexpr int WIDE_CAP = 2048;  // contender slots
+
+template <int WL>
+__global__ __launch_bounds__(WIDE_NT) void beam_records_wide_kernel(RecArgs p, int* overflow) {
+  constexpr int RL = 2 + 2 * WL;
+  constexpr int NWV = WIDE_NT / 64;
+  constexpr int MAXW = ICAP_MAX_BEAM_WIDTH;
+  static_assert(NWV >= MAXW, "one wave per beam row");
+  __shared__ float s_M[MAXW], s_L[MAXW], s_lp[MAXW];
+  __shared__ int s_len[MAXW], s_fin[MAXW];
+  __shared__ float s_top[NWV * MAXW];
+  __shared__ float s_thr;
+  __shared__ float l_s[WIDE_CAP], l_t[WIDE_CAP];
+  __shared__ int l_i[WIDE_CAP];
+  __shared__ int l_n, s_over;
+  const int W = p.W, V = p.V, HT = p.HT;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool first = p.time <= 0;
+  const int n_rows = first ? 1 : W;  // time 0 scores beam 0 only
+  const int n_rec = n_rows * HT;
+  const size_t row0 = (size_t)b * W;
+  const float* rec0 = p.rec + (size_t)b * p.rpi * HT * RL;
+
+  if (tid < MAXW) {
+    const bool ok = tid < n_rows;
+    s_lp[tid] = p.log_probs[row0 + (ok ? tid : 0)];
+    s_len[tid] = p.lengths[row0 + (ok ? tid : 0)];
+    s_fin[tid] = ok ? (p.finished[row0 + tid] != 0 ? 1 : 0) : 1;
+  }
+  if (tid == 0) { l_n = 0; s_over = 0; }
+
+  // ---- A: row statistics, wave w <- row w ----
+  if (wave < n_rows) {
+    float m = -INFINITY, sm = 0.f;
+    for (int h = lane; h < HT; h += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(rec0 + ((size_t)wave * HT + h) * RL);
+      if (v.x > -INFINITY) {
+        const float nm = fmaxf(m, v.x);
+        sm = sm * fast_exp(m - nm) + v.y * fast_exp(v.x - nm);  // (m = -inf: sm is 0, exp gives 0)
+        m = nm;
+      }
+    }
+    const float M = wave_max(m);
+    const float tot = wave_sum((m > -INFINITY) ? sm * fast_exp(m - M) : 0.f);
+    if (lane == 0) { s_M[wave] = M; s_L[wave] = logf(tot); }
+  }
+  __syncthreads();
+
+  // ---- B: lower bound on the W-th best score from the records' best logits ----
+  float tmax = -INFINITY;
+  for (int idx = tid; idx < n_rec; idx += WIDE_NT) {
+    const int w = idx / HT;
+    if (s_fin[w]) continue;
+    const float* r = rec0 + (size_t)idx * RL;
+    const float x = r[2];
+    const int col = __float_as_int(r[2 + WL]);
+    const float tot = s_lp[w] + ((x - s_M[w]) - s_L[w]);
+    const float sc = tot / penalty_of(p.pen, s_len[w] + 1);
+    if (col >= 0 && col < V && col != p.eos && sc == sc) tmax = fmaxf(tmax, sc);
+  }
+  {
+    float v[1] = {tmax};
+    float top[MAXW];
+    wave_kth_largest<MAXW, 1>(v, lane, top);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MAXW; ++k) s_top[wave * MAXW + k] = top[k];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr int PERV = NWV * MAXW / 64;
+    float v[PERV];
+#pragma unroll
+    for (int q = 0; q < PERV; ++q) v[q] = s_top[lane + 64 * q];
+    // the W-th largest: W rounds, each removing one instance of the maximum
+    float kth = -INFINITY;
+    for (int r = 0; r < W; ++r) {
+      float m = v[0];
+#pragma unroll
+      for (int q = 1; q < PERV; ++q) m = fmaxf(m, v[q]);
+      const float top = wave_max(m);
+      kth = top;
+      const unsigned long long owners = __ballot(m == top);
+      if (owners != 0 && lane == (int)__builtin_ctzll(owners)) {
+        bool done = false;
+#pragma unroll
+        for (int q = 0; q < PERV; ++q)
+          if (!done && v[q] == top) { v[q] = -INFINITY; done = true; }
+      }
+    }
+    if (lane == 0) s_thr = kth;
+  }
+  __syncthreads();
+  const float thr = s_thr;  // -inf when fewer than W live candidates exist: everything contends
+
+  // ---- C: contenders ----
+  for (int idx = tid; idx < n_rec; idx += WIDE_NT) {
+    const int w = idx / HT;
+    if (s_fin[w]) continue;
+    const float4* r4 = reinterpret_cast<const float4*>(rec0 + (size_t)idx * RL);
+    float4 q4[RL / 4];
+#pragma unroll
+    for (int q = 0; q < RL / 4; ++q) q4[q] = r4[q];
+    const float* fl = reinterpret_cast<const float*>(&q4[0]);
+    const float lp = s_lp[w], M = s_M[w], lse = s_L[w];
+    const float pen_oth = penalty_of(p.pen, s_len[w] + 1);
+    const int flat0 = first ? 0 : w * V;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const float x = fl[2 + k];
+      const int col = __float_as_int(fl[2 + WL + k]);
+      const float tot = lp + ((x - M) - lse);
+      const float sc = tot / pen_oth;
+      const bool in_range = col >= 0 && col < V;
+      // (the eos column is scored by its row's synthetic candidate, with its own penalty)
+      if (in_range && sc == sc && sc >= thr) {
+        if (k == WL - 1) s_over = 1;  // the record may hide logits that reach the bound too
+        if (col != p.eos) {
+          const int slot = atomicAdd(&l_n, 1);
+          if (slot < WIDE_CAP) { l_s[slot] = sc; l_t[slot] = tot; l_i[slot] = flat0 + col; }
+        }
+      }
+    }
+  }
+  // synthetic candidates: thread w*(W+2)+j makes the j-th candidate of a finished row w (all
+  // its mass on eos: only the first W+1 columns and eos can be selected) and, for j == 0, the
+  // eos candidate of a live row
+  {
+    const int sp_w = tid / (W + 2), sp_j = tid - sp_w * (W + 2);
+    if (sp_w < n_rows) {
+      const float lp = s_lp[sp_w];
+      const int flat0 = first ? 0 : sp_w * V;
+      const float pen = penalty_of(p.pen, s_len[sp_w]);
+      float sc = -INFINITY, tot = 0.f;
+      int fi = EMPTY_IDX;
+      if (s_fin[sp_w]) {
+        const int ncol = min(V, W + 1);
+        int col = -1;
+        if (sp_j < ncol) col = sp_j;
+        else if (sp_j == ncol && p.eos >= ncol && p.eos < V) col = p.eos;
+        if (col >= 0) {
+          tot = lp + ((col == p.eos) ? 0.f : kF32Min);
+          sc = tot / pen;
+          fi = flat0 + col;
+        }
+      } else if (sp_j == 0 && p.eos >= 0 && p.eos < V) {
+        const float ex = p.eos_x[(size_t)b * p.rpi + sp_w];
+        tot = lp + ((ex - s_M[sp_w]) - s_L[sp_w]);
+        sc = tot / pen;
+        fi = (sc == sc) ? flat0 + p.eos : EMPTY_IDX;
+      }
+      if (fi != EMPTY_IDX) {
+        const int slot = atomicAdd(&l_n, 1);
+        if (slot < WIDE_CAP) { l_s[slot] = sc; l_t[slot] = tot; l_i[slot] = fi; }
+      }
+    }
+  }
+  __syncthreads();
+  const int n_list = l_n;
+  if (tid == 0 && (s_over != 0 || n_list > WIDE_CAP)) *overflow = 1;
+  if (wave != 0) return;
+
+  // ---- D: W winners (score descending, lower flat index first); lane r keeps winner r ----
+  const int n = min(n_list, WIDE_CAP);
+  float my_s = -INFINITY, my_t = 0.f;
+  int my_i = EMPTY_IDX;
+  for (int r = 0; r < W; ++r) {
+    float bs = -INFINITY, bt = 0.f;
+    int bi = EMPTY_IDX, bslot = -1;
+    for (int q = lane; q < n; q += 64) {
+      const float cs_ = l_s[q];
+      const int ci_ = l_i[q];
+      if (cand_better(cs_, ci_, bs, bi)) { bs = cs_; bt = l_t[q]; bi = ci_; bslot = q; }
+    }
+    const int own = bi;
+    wave_best(bs, bt, bi);
+    if (bi != EMPTY_IDX && own == bi && bslot >= 0) l_i[bslot] = EMPTY_IDX;  // flat indices are unique
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round reads the list again
+    if (lane == r) { my_s = bs; my_t = bt; my_i = bi; }
+  }
+  const bool act = lane < W;
+  const int flat = (my_i == EMPTY_IDX) ? 0 : my_i;
+  const int word = flat % V;
+  const int parent = flat / V;
+  const int pfin = s_fin[parent < MAXW ? parent : 0];
+  const int plen = s_len[parent < MAXW ? parent : 0];
+  const int nfin = (pfin || word == p.eos) ? 1 : 0;
+  const int nlen = plen + ((word != p.eos && !nfin) ? 1 : 0);
+  if (act) {
+    const size_t o = row0 + lane;
+    p.scores[o] = my_s;
+    p.ids[o] = word;
+    p.parents[o] = parent;
+    p.next_lp[o] = my_t;
+    p.next_fin[o] = (uint8_t)nfin;
+    p.next_len[o] = nlen;
+  }
+}
+
 // ---- back-tracking: one thread per image ----
 __global__ __launch_bounds__(256) void backtrack_kernel(const int32_t* __restrict__ ids,
                                                         const int32_t* __restrict__ parents,
@@ -815,7 +1038,8 @@ int beam_step_rows_f32(const float* logits, const float* log_probs, const uint8_
                        double length_penalty_weight, int input_is_log_prob, float* scores,
                        int32_t* predicted_ids, int32_t* parent_ids, float* next_log_probs,
                        uint8_t* next_finished, int32_t* next_lengths, int B, int R, int W, int V,
-                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+                       void* workspace, size_t workspace_bytes, hipStream_t s,
+                       const int* run_flag, int* clear_flag) {
   ICAP_REQUIRE(logits && log_probs && finished && lengths, "beam_step_f32: null input");
   ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
                    next_lengths,
@@ -848,6 +1072,8 @@ int beam_step_rows_f32(const float* logits, const float* log_probs, const uint8_
   a.ws_total = a.ws_score + rows * WL_MAX;
   a.ws_idx = reinterpret_cast<int*>(a.ws_total + rows * WL_MAX);
   a.pen = make_penalty(length_penalty_weight);
+  a.run_flag = run_flag;
+  a.clear_flag = clear_flag;
   const bool vec = (V % 4 == 0) && aligned16(logits);
   const int wl = W > R ? W : R;  // candidate slots per row: the winners and the rows both fit
   if (wl <= 1) return dispatch_beam<1>(a, vec, s);
@@ -866,7 +1092,7 @@ int beam_step_f32(const float* logits, const float* log_probs, const uint8_t* fi
   return beam_step_rows_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
                             length_penalty_weight, input_is_log_prob, scores, predicted_ids,
                             parent_ids, next_log_probs, next_finished, next_lengths, B, W, W, V,
-                            workspace, workspace_bytes, s);
+                            workspace, workspace_bytes, s, nullptr, nullptr);
 }
 
 // ---- the beam step for callers that cannot allocate -------------------------------------
@@ -921,7 +1147,7 @@ int beam_step_static_f32(const float* logits, const float* log_probs, const uint
   return beam_step_rows_f32(logits, log_probs, finished, lengths, time, start_offset, eos_token,
                             length_penalty_weight, input_is_log_prob, scores, predicted_ids,
                             parent_ids, next_log_probs, next_finished, next_lengths, B, W, W, V, ws,
-                            STATIC_WS_BYTES, s);
+                            STATIC_WS_BYTES, s, nullptr, nullptr);
 }
 
 // Records one workgroup can hold in registers (8 per thread); more take the unfused kernels.
@@ -973,6 +1199,50 @@ int beam_step_from_records_f32(const float* records, const float* eos_logit, int
   else { ICAP_REC_LAUNCH(5) }
 #undef ICAP_REC_LAUNCH
   ICAP_LAUNCH_CHECK("beam_records_kernel");
+  return ICAP_OK;
+}
+
+// The fused step for beams wider than the records are deep (W <= ICAP_MAX_BEAM_WIDTH on
+// records of top_k = 5 logits per half tile).  *overflow (device word, zero on entry) is set
+// when the records cannot prove the result for some image; the outputs are then to be
+// recomputed from full logits (beam_step_f32).
+int beam_step_from_records_wide_f32(const float* records, const float* eos_logit, int half_tiles,
+                                    int top_k, const float* log_probs, const uint8_t* finished,
+                                    const int32_t* lengths, int time, int eos_token,
+                                    double length_penalty_weight, float* scores,
+                                    int32_t* predicted_ids, int32_t* parent_ids,
+                                    float* next_log_probs, uint8_t* next_finished,
+                                    int32_t* next_lengths, int B, int W, int V, int* overflow,
+                                    hipStream_t s, int compact_first) {
+  ICAP_REQUIRE(records && eos_logit && log_probs && finished && lengths && overflow,
+               "beam_step_from_records_wide_f32: null input");
+  ICAP_REQUIRE(scores && predicted_ids && parent_ids && next_log_probs && next_finished &&
+                   next_lengths,
+               "beam_step_from_records_wide_f32: null output");
+  ICAP_REQUIRE(B > 0 && V > 0 && half_tiles > 0, "beam_step_from_records_wide_f32: bad shape");
+  ICAP_REQUIRE(top_k == 5, "beam_step_from_records_wide_f32: top_k must be 5 (got %d)", top_k);
+  ICAP_REQUIRE(W >= 1 && W <= ICAP_MAX_BEAM_WIDTH,
+               "beam_step_from_records_wide_f32: beam width %d outside [1,%d]", W,
+               ICAP_MAX_BEAM_WIDTH);
+  ICAP_REQUIRE(W <= V && (long long)W * V < (1LL << 31), "beam_step_from_records_wide_f32: bad W, V");
+  ICAP_REQUIRE((long long)W * half_tiles < (1LL << 24),
+               "beam_step_from_records_wide_f32: too many records per image");
+  ICAP_REQUIRE(next_finished != finished && next_lengths != lengths,
+               "beam_step_from_records_wide_f32: the next state must not alias the state (a "
+               "recomputation after an overflow reads the old one)");
+  ICAP_REQUIRE(!compact_first || time <= 0,
+               "beam_step_from_records_wide_f32: one record row per image only serves time 0");
+  RecArgs a;
+  a.rec = records; a.eos_x = eos_logit; a.HT = half_tiles;
+  a.rpi = compact_first ? 1 : W;
+  a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
+  a.time = time; a.eos = eos_token;
+  a.scores = scores; a.ids = predicted_ids; a.parents = parent_ids;
+  a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
+  a.B = B; a.W = W; a.V = V;
+  a.pen = make_penalty(length_penalty_weight);
+  hipLaunchKernelGGL(beam_records_wide_kernel<5>, dim3(B), dim3(WIDE_NT), 0, s, a, overflow);
+  ICAP_LAUNCH_CHECK("beam_records_wide_kernel");
   return ICAP_OK;
 }
 

@@ -93,7 +93,15 @@ int beam_step_f32(const float*, const float*, const uint8_t*, const int32_t*, in
                   int, void*, size_t, hipStream_t);
 int beam_step_rows_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
                        double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
-                       int, int, void*, size_t, hipStream_t);
+                       int, int, void*, size_t, hipStream_t, const int* run_flag = nullptr,
+                       int* clear_flag = nullptr);
+int beam_step_from_records_wide_f32(const float*, const float*, int, int, const float*, const uint8_t*,
+                                    const int32_t*, int, int, double, float*, int32_t*, int32_t*,
+                                    float*, uint8_t*, int32_t*, int, int, int, int*, hipStream_t,
+                                    int compact_first = 0);
+bool dense_f32_flagged_supported(const float*, const float*, int, int, int, int);
+int dense_f32_flagged(const float*, int, const float*, const float*, float*, int, int, int, const int*,
+                      hipStream_t);
 size_t beam_step_workspace_bytes(int B, int W);
 int beam_step_static_f32(const float*, const float*, const uint8_t*, const int32_t*, int, int, int,
                          double, int, float*, int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int,
@@ -145,6 +153,15 @@ struct icap_engine {
   int topk = 0;       // 0: unfused (logits buffer + beam_step kernels)
   int topk_able = 0;  // the top_k the fused path would use for this shape (0: not served)
   float *rec = nullptr, *eos_x = nullptr;
+  // Beams wider than the records are deep (W > 5 on records of 5 logits per half tile): the
+  // beam kernel proves per image that no unrecorded logit matters and raises a device flag
+  // otherwise; the unfused projection + beam step are enqueued behind it and do nothing
+  // unless the flag is up.  The step then needs the state it started from: fin / len ping-pong.
+  bool wide = false;
+  int* flags = nullptr;        // two words (step parity), in a 256-byte block of their own
+  uint8_t* fin2 = nullptr;
+  int32_t* len2 = nullptr;
+  long wide_rescues_forced = 0;  // test hook: raise the flag at every step
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr, ev_gate = nullptr;
@@ -269,6 +286,11 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const bool gru = c.cell == ICAP_CELL_GRU;
   e->timing = (e->decode_calls++ % e->timing_every == 0) ? e->timing_mask : 0u;
 
+  // the wide fused step has no masked form: the searcher's loop takes the unfused kernels there
+  const int topk = (e->wide && (lv.mask_start || lv.seq_len)) ? 0 : e->topk;
+  const bool wide = topk != 0 && e->wide;
+  uint8_t* fin = e->fin;  // beam state of the current step (the wide step ping-pongs it)
+  int32_t* len = e->len;
   const float* features = lv.features ? lv.features : e->features;
   if (!lv.features) {  // K0: features = relu(img . Wenc + benc)
     Timed t(e, ICAP_K_ENCODE, s);
@@ -308,6 +330,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     ICAP_HIP(hipMemsetAsync(e->lp, 0, sizeof(float) * N, s));
     ICAP_HIP(hipMemsetAsync(e->len, 0, sizeof(int32_t) * N, s));
     ICAP_HIP(hipMemsetAsync(e->fin, 0, N, s));
+    if (wide) ICAP_HIP(hipMemsetAsync(e->flags, 0, 256, s));
   }
 
   const int stride_g = c.tile_mode == ICAP_TILE_REPEAT ? c.W : 1;
@@ -367,13 +390,13 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // Exact-f32 fused path: query_{t+1} + attention_{t+1} are the first workgroups of the
   // vocab_t launch instead (dense_topk_attention_f32), everything on the caller's stream:
   //   main: lstm_t -> fc1_t -> [attention_{t+1} | vocab_t] -> beam_t -> lstm_{t+1} ...
-  const bool merged = e->merged && e->overlap && e->topk != 0;
+  const bool merged = e->merged && e->overlap && topk != 0 && !wide;
   const bool side = e->overlap && !merged;
   const int att_blocks = e->side_att_wgs > 0 ? e->side_att_wgs : c.B;
   auto vocab_with_attention = [&](const float* x, int lda, int rows, const LogitMasks* mk,
                                   const float* state) -> int {
     return dense_topk_attention_f32(x, lda, w.fc2_kernel, w.fc2_bias, rows, c.H, c.V, c.eos_id,
-                                    e->topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
+                                    topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
                                     e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
                                     w.att_w2_kernel, w.att_w2_bias, e->ctx, c.B, c.W, stride_g,
                                     stride_k, c.L, c.U, c.D, c.H, att_blocks, s);
@@ -415,7 +438,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     const int bs_time = t + lv.time_offset;  // the beam step ranks beam 0 only at time 0
     masks.step1 = bs_time + 1;
     const LogitMasks* mk = masks.any() ? &masks : nullptr;
-    if (e->topk && bs_time == 0 && c.W > 1 && c.precision == ICAP_PRECISION_FP32 && !mk) {
+    // wide step: outputs of the state go to the other buffer pair, the flag of this step's parity
+    uint8_t* fin_o = wide ? (fin == e->fin ? e->fin2 : e->fin) : fin;
+    int32_t* len_o = wide ? (len == e->len ? e->len2 : e->len) : len;
+    int* flag = wide ? e->flags + (t & 1) : nullptr;
+    int* flag_next = wide ? e->flags + ((t + 1) & 1) : nullptr;
+    if (topk && bs_time == 0 && c.W > 1 && c.precision == ICAP_PRECISION_FP32 && !mk) {
       // Time 0 ranks the candidates of beam 0 only (beam_search.py:451-455), so fc1 and the
       // vocab projection run on every W-th row (row stride W*H) and write one record row per
       // image; the recurrent state of all rows was still advanced above.
@@ -430,14 +458,36 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           ICAP_TRY(vocab_with_attention(e->fc1o, c.H, c.B, nullptr, gru ? e->h[cur] : e->c));
         else
           ICAP_TRY(dense_topk_f32_strided(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V,
-                                          c.eos_id, e->topk, e->rec, e->eos_x, nullptr, s));
+                                          c.eos_id, topk, e->rec, e->eos_x, nullptr, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
       Timed tm(e, ICAP_K_BEAM, s);
+      if (wide) {
+        ICAP_TRY(beam_step_from_records_wide_f32(
+            e->rec, e->eos_x, dense_topk_half_tiles(c.V), topk, lp_in, fin, len, 0, c.eos_id,
+            c.length_penalty_weight, e->hist_scores, e->hist_ids, e->hist_parents, e->hist_lp, fin_o,
+            len_o, c.B, c.W, c.V, flag, s, 1));
+        if (e->wide_rescues_forced) {
+          hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, flag, 1, 1);
+          ICAP_LAUNCH_CHECK("fill_i32_kernel");
+        }
+        // behind it, switched off on the device unless the flag is up: the same step on the
+        // full logits of beam 0 ([B,1,V]; the state before step 0 is all zeros, so its first
+        // B entries serve as the [B,1] state)
+        ICAP_TRY(dense_f32_flagged(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, e->logits, c.B, c.H, c.V,
+                                   flag, s));
+        ICAP_TRY(beam_step_rows_f32(e->logits, lp_in, fin, len, 0, 0, c.eos_id,
+                                    c.length_penalty_weight, 0, e->hist_scores, e->hist_ids,
+                                    e->hist_parents, e->hist_lp, fin_o, len_o, c.B, 1, c.W, c.V,
+                                    e->beam_ws, e->beam_ws_bytes, s, flag, flag_next));
+        fin = fin_o;
+        len = len_o;
+        continue;
+      }
       ICAP_TRY(beam_step_from_records_f32(
-          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, 0, c.eos_id,
-          c.length_penalty_weight, e->hist_scores, e->hist_ids, e->hist_parents, e->hist_lp, e->fin,
-          e->len, c.B, c.W, c.V, s, 1));
+          e->rec, e->eos_x, dense_topk_half_tiles(c.V), topk, lp_in, fin, len, 0, c.eos_id,
+          c.length_penalty_weight, e->hist_scores, e->hist_ids, e->hist_parents, e->hist_lp, fin,
+          len, c.B, c.W, c.V, s, 1));
       continue;
     }
     {  // K7: fc1
@@ -445,7 +495,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
                             c.H, c.H, ICAP_ACT_NONE, s));
     }
-    if (e->topk) {
+    if (topk) {
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
       if (t + 1 < c.T && side && vocab_gate && !((e->timing >> ICAP_K_VOCAB) & 1u))
         ICAP_HIP(hipEventRecord(e->ev_gate, s));
@@ -453,23 +503,45 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         Timed tm(e, ICAP_K_VOCAB, s);
         if (c.precision == ICAP_PRECISION_BF16)
           ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
-                                   c.eos_id, e->topk, e->rec, e->eos_x, mk, s));
+                                   c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (c.precision == ICAP_PRECISION_F32_SPLIT)
           ICAP_TRY(dense_topk_split(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
-                                    c.eos_id, e->topk, e->rec, e->eos_x, mk, s));
+                                    c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (merged && t + 1 < c.T)
           ICAP_TRY(vocab_with_attention(e->fc1o, c.H, N, mk, gru ? e->h[cur] : e->c));
         else
           ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
-                                  e->topk, e->rec, e->eos_x, mk, s));
+                                  topk, e->rec, e->eos_x, mk, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
       Timed tm(e, ICAP_K_BEAM, s);
+      if (wide) {
+        ICAP_TRY(beam_step_from_records_wide_f32(
+            e->rec, e->eos_x, dense_topk_half_tiles(c.V), topk, lp_in, fin, len, bs_time, c.eos_id,
+            c.length_penalty_weight, e->hist_scores + (size_t)t * N, e->hist_ids + (size_t)t * N,
+            e->hist_parents + (size_t)t * N, e->hist_lp + (size_t)t * N, fin_o, len_o, c.B, c.W,
+            c.V, flag, s));
+        if (e->wide_rescues_forced) {
+          hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, flag, 1, 1);
+          ICAP_LAUNCH_CHECK("fill_i32_kernel");
+        }
+        // behind it, switched off on the device unless the flag is up: the unfused step
+        ICAP_TRY(dense_f32_flagged(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, e->logits, N, c.H, c.V,
+                                   flag, s));
+        ICAP_TRY(beam_step_rows_f32(e->logits, lp_in, fin, len, bs_time, 0, c.eos_id,
+                                    c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
+                                    e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
+                                    e->hist_lp + (size_t)t * N, fin_o, len_o, c.B, c.W, c.W, c.V,
+                                    e->beam_ws, e->beam_ws_bytes, s, flag, flag_next));
+        fin = fin_o;
+        len = len_o;
+        continue;
+      }
       ICAP_TRY(beam_step_from_records_f32(
-          e->rec, e->eos_x, dense_topk_half_tiles(c.V), e->topk, lp_in, e->fin, e->len, bs_time,
+          e->rec, e->eos_x, dense_topk_half_tiles(c.V), topk, lp_in, fin, len, bs_time,
           c.eos_id,
           c.length_penalty_weight, e->hist_scores + (size_t)t * N, e->hist_ids + (size_t)t * N,
-          e->hist_parents + (size_t)t * N, e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W,
+          e->hist_parents + (size_t)t * N, e->hist_lp + (size_t)t * N, fin, len, c.B, c.W,
           c.V, s));
       continue;
     }
@@ -483,16 +555,16 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     {  // K9: beam step.  Outputs and the accumulated log-probs are recorded per step; the
        // log-probs of step t-1 are the state input of step t (zeros at t = 0).
       Timed tm(e, ICAP_K_BEAM, s);
-      ICAP_TRY(beam_step_f32(e->logits, lp_in, e->fin, e->len, bs_time, 0, c.eos_id,
+      ICAP_TRY(beam_step_f32(e->logits, lp_in, fin, len, bs_time, 0, c.eos_id,
                              c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
                              e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
-                             e->hist_lp + (size_t)t * N, e->fin, e->len, c.B, c.W, c.V,
+                             e->hist_lp + (size_t)t * N, fin, len, c.B, c.W, c.V,
                              e->beam_ws, e->beam_ws_bytes, s));
     }
   }
   {  // K10
     Timed tm(e, ICAP_K_BACKTRACK, s);
-    ICAP_TRY(backtrack(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N, e->fin,
+    ICAP_TRY(backtrack(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N, fin,
                        tokens, nullptr, best_score, c.T, c.B, c.W, s));
   }
   return ICAP_OK;
@@ -723,6 +795,22 @@ int icap_beam_step_from_records_f32(const float* records, const float* eos_logit
                                     next_lengths, B, W, V, (hipStream_t)stream);
 }
 
+int icap_beam_step_from_records_wide_f32(const float* records, const float* eos_logit,
+                                         int half_tiles, int top_k, const float* log_probs,
+                                         const uint8_t* finished, const int32_t* lengths, int time,
+                                         int eos_token, double length_penalty_weight, float* scores,
+                                         int32_t* predicted_ids, int32_t* parent_ids,
+                                         float* next_log_probs, uint8_t* next_finished,
+                                         int32_t* next_lengths, int B, int W, int V,
+                                         int32_t* overflow, int compact_first,
+                                         icap_stream_t stream) {
+  return beam_step_from_records_wide_f32(records, eos_logit, half_tiles, top_k, log_probs, finished,
+                                         lengths, time, eos_token, length_penalty_weight, scores,
+                                         predicted_ids, parent_ids, next_log_probs, next_finished,
+                                         next_lengths, B, W, V, overflow, (hipStream_t)stream,
+                                         compact_first);
+}
+
 int icap_backtrack(const int32_t* ids, const int32_t* parents, const float* last_scores,
                    const uint8_t* last_finished, int32_t* tokens, int32_t* best_beam,
                    float* best_score, int T, int B, int W, icap_stream_t stream) {
@@ -761,6 +849,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
   const size_t o_rl = cv.take<int32_t>(N);
+  const size_t o_fin2 = cv.take<uint8_t>(N), o_len2 = cv.take<int32_t>(N), o_flags = cv.take<char>(256);
   const bool gru = c.cell == ICAP_CELL_GRU;
   const size_t o_gk = cv.take<float>(gru ? (size_t)(c.D + c.E) * 4 * c.H : 0),
                o_gr = cv.take<float>(gru ? (size_t)c.H * 4 * c.H : 0),
@@ -783,6 +872,15 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const bool shape_ok =
         c.W <= 5 && gemm_ok && beam_records_supported(c.W, dense_topk_half_tiles(c.V), tk);
     e->topk_able = shape_ok ? tk : 0;
+    // wider beams (exact-f32 only): records of 5 with the proof-or-repeat beam step
+    if (c.W > 5 && c.precision == ICAP_PRECISION_FP32 && gemm_ok &&
+        dense_f32_flagged_supported(weights->fc2_kernel, weights->fc2_kernel, c.H, (int)N, c.H, c.V) &&
+        (long long)c.W * dense_topk_half_tiles(c.V) < (1LL << 24)) {
+      e->wide = true;
+      e->topk_able = 5;
+      const char* force_env = getenv("ICAP_FORCE_WIDE_RESCUE");  // test hook, read per engine
+      e->wide_rescues_forced = force_env && force_env[0] == '1';
+    }
     // The fused projection works in 128x128 tiles; below about three of them per compute
     // unit the plain projection (64x64 tiles, or the small-batch form) plus the unfused beam
     // step is faster: measured at beam 3, B = 32 / 128 / 256 / 384 / 512: 15.5k / 42k / 65k /
@@ -870,6 +968,9 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
   e->row_len = (int32_t*)(b + o_rl);
+  e->fin2 = (uint8_t*)(b + o_fin2);
+  e->len2 = (int32_t*)(b + o_len2);
+  e->flags = (int*)(b + o_flags);
   if (gru) {
     e->gru_k4 = (float*)(b + o_gk);
     e->gru_r4 = (float*)(b + o_gr);
@@ -1035,7 +1136,8 @@ int icap_engine_set_fused_vocab(icap_engine* e, int on) {
   if (on && !e->topk_able)
     return fail(ICAP_ERR_UNSUPPORTED,
                 "icap_engine_set_fused_vocab: this engine's shape or precision is not served by "
-                "the fused projection (beam width <= 5; fp32: vocab %% 4 == 0, H %% 32 == 0)");
+                "the fused projection (fp32: vocab %% 4 == 0, H %% 32 == 0; beam width <= 5 in the "
+                "bf16 and split modes)");
   e->topk = on ? e->topk_able : 0;
   return ICAP_OK;
 }

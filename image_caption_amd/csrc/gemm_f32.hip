@@ -42,6 +42,9 @@ struct DenseArgs {
   float* eos_x;  // [M]: the logit of column `eos`
   int eos;
   LogitMasks masks;  // additive masks applied before the records are built (default: none)
+  // Device-side switch (engine only, null otherwise): the launch does nothing unless
+  // *run_flag != 0.
+  const int* run_flag = nullptr;
 };
 
 // Guarded 4-float load without control flow: the address is clamped to `safe` (any
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
     __attribute__((amdgpu_waves_per_eu(WM * WN * MINW / 4, WM * WN * MINW / 4)))
     void dense_f32_fast_kernel(DenseArgs p) {
   __shared__ typename FastLds<BM, BN, WM, WN, TOPK>::U lds;
+  if (p.run_flag != nullptr && *p.run_flag == 0) return;
   dense_fast_body<BM, BN, WM, WN, TOPK>(p, blockIdx.x, lds);
 }
 
@@ -1313,6 +1317,26 @@ int dense_f32_strided(const float* x, int lda, const float* w, const float* bias
     }
   }
   return launch_dense<64, 64, 2, 2, 2>(a, vec, s);
+}
+
+// dense_f32_strided on the 128x128 tile kernel whatever the shape (the kernel and the sums of
+// dense_topk_f32), switched on the device: nothing runs unless *run_flag != 0.  The engine
+// enqueues it behind the fused projection + wide beam step, which raises the flag when its
+// records cannot prove the step's result.
+bool dense_f32_flagged_supported(const float* x, const float* w, int lda, int M, int K, int N) {
+  return M > 0 && K > 0 && N > 0 && K % BK == 0 && N % 4 == 0 && lda % 4 == 0 && aligned16(x) &&
+         aligned16(w) && (long long)M * lda < (1LL << 31) && (long long)K * N < (1LL << 31);
+}
+
+int dense_f32_flagged(const float* x, int lda, const float* w, const float* bias, float* y, int M,
+                      int K, int N, const int* run_flag, hipStream_t s) {
+  ICAP_REQUIRE(x && w && y && run_flag, "dense_f32_flagged: null pointer");
+  ICAP_REQUIRE(lda >= K && dense_f32_flagged_supported(x, w, lda, M, K, N),
+               "dense_f32_flagged: shape not served (M=%d K=%d N=%d lda=%d)", M, K, N, lda);
+  DenseArgs a{x, w, bias, y, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};
+  a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  a.run_flag = run_flag;
+  return launch_dense<128, 128, 4, 2, 2>(a, true, s);
 }
 
 // Records per row and floats per record of dense_topk_f32 (0 when the shape is not served).

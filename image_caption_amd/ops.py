@@ -500,6 +500,32 @@ def dense_topk(x, kernel, bias, eos_token, top_k):
     return rec, eos_logit
 
 
+def beam_step_from_records_wide(rec, eos_logit, log_probs, finished, lengths, time, eos_token,
+                                length_penalty_weight, V, compact_first=False):
+    """The records step for beams up to 16 wide on records of 5 logits per half tile.
+    Returns the six outputs of beam_step plus the overflow word (int32 [1]; non-zero: the
+    records could not prove the result, repeat the step on full logits)."""
+    B, W = log_probs.shape
+    dev = log_probs.device
+    scores = torch.empty(B, W, dtype=f32, device=dev)
+    ids = torch.empty(B, W, dtype=i32, device=dev)
+    parents = torch.empty(B, W, dtype=i32, device=dev)
+    nlp = torch.empty(B, W, dtype=f32, device=dev)
+    nfin = torch.empty(B, W, dtype=u8, device=dev)
+    nlen = torch.empty(B, W, dtype=i32, device=dev)
+    overflow = torch.zeros(1, dtype=i32, device=dev)
+    HT, RL = rec.shape[1], rec.shape[2]
+    if RL != 12:
+        raise ValueError("beam_step_from_records_wide: records must hold 5 logits per half tile")
+    _call("icap_beam_step_from_records_wide_f32", _chk(rec, f32, "rec"), _chk(eos_logit, f32, "eos_logit"),
+          HT, 5, _chk(log_probs, f32, "log_probs"), _chk(finished, u8, "finished"),
+          _chk(lengths, i32, "lengths"), int(time), int(eos_token), float(length_penalty_weight),
+          scores.data_ptr(), ids.data_ptr(), parents.data_ptr(), nlp.data_ptr(), nfin.data_ptr(),
+          nlen.data_ptr(), B, W, int(V), overflow.data_ptr(), 1 if compact_first else 0,
+          current_stream())
+    return scores, ids, parents, nlp, nfin, nlen, overflow
+
+
 def beam_step_from_records(rec, eos_logit, log_probs, finished, lengths, time, eos_token,
                            length_penalty_weight, V):
     """beam_step on the records of dense_topk; state tensors [B, W]."""

@@ -290,8 +290,9 @@ int icap_hyp_score_f32(const float* log_probs, const int32_t* lengths,
 int icap_batch_gather_f32(const float* a, const int32_t* idx, float* out, int B, int X,
                           int Y, icap_stream_t stream);
 
-/* Fused form of the vocab projection and the beam step, used by the engine when the
- * beam width is at most 5: the [M,N] logits are never written to memory.
+/* Fused form of the vocab projection and the beam step (the engine's default from about
+ * three 128x128 projection tiles per compute unit upwards): the [M,N] logits are never
+ * written to memory.
  * icap_dense_topk_f32 computes x[M,K] . w[K,N] + bias like icap_dense_f32 (same kernel,
  * same sums) but its epilogue keeps, for every row and every 64-column half tile, one
  * record of icap_dense_topk_record_floats(top_k) = 2 + 2*top_k floats:
@@ -317,6 +318,27 @@ int icap_beam_step_from_records_f32(const float* records, const float* eos_logit
                                     int32_t* parent_ids, float* next_log_probs,
                                     uint8_t* next_finished, int32_t* next_lengths,
                                     int B, int W, int V, icap_stream_t stream);
+
+/* The same step for beam widths up to ICAP_MAX_BEAM_WIDTH on records that hold fewer logits
+ * per half tile than the beam is wide (top_k = 5 only).  A half tile may then hide a
+ * candidate; the kernel proves per image that none of the hidden ones can be among the W
+ * successors (the last logit a record holds scores below a lower bound on the W-th best
+ * score) and sets *overflow = 1 (device int32, zero on entry) where it cannot.  With
+ * *overflow == 0 afterwards the outputs are those of icap_beam_step_f32 on the full logits;
+ * otherwise the caller repeats the step there (the engine enqueues that repetition behind
+ * this call, switched off on the device while the flag is down).  The next_* buffers must
+ * not alias the state inputs.  compact_first != 0: time 0 on one record row per image
+ * (only beam 0 was projected).  Same reference call sites as
+ * icap_beam_step_from_records_f32. */
+int icap_beam_step_from_records_wide_f32(const float* records, const float* eos_logit,
+                                         int half_tiles, int top_k, const float* log_probs,
+                                         const uint8_t* finished, const int32_t* lengths,
+                                         int time, int eos_token, double length_penalty_weight,
+                                         float* scores, int32_t* predicted_ids,
+                                         int32_t* parent_ids, float* next_log_probs,
+                                         uint8_t* next_finished, int32_t* next_lengths,
+                                         int B, int W, int V, int32_t* overflow,
+                                         int compact_first, icap_stream_t stream);
 
 /* Back-tracking over T recorded steps: pick the best final beam per image
  * (unfinished beams get -1e9 when any beam of the image is finished, first max
@@ -442,8 +464,9 @@ int icap_engine_set_timing_every(icap_engine* engine, int n);
 int icap_engine_set_overlap(icap_engine* engine, int on);
 /* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
  * icap_beam_step_from_records_f32; in bf16 mode the bf16 projection writes the same
- * records) whenever its shape is served: beam width <= 5 and, for fp32, V % 4 == 0,
- * H % 32 == 0.  on == 0 selects the unfused kernels (a [B*W,V] logits buffer,
+ * records) whenever its shape is served: for fp32 V % 4 == 0, H % 32 == 0 (beams wider than 5
+ * through icap_beam_step_from_records_wide_f32 and its repetition on full logits); beam
+ * width <= 5 in the bf16 and split modes.  on == 0 selects the unfused kernels (a [B*W,V] logits buffer,
  * icap_dense_f32 + icap_beam_step_f32); on != 0 returns ICAP_ERR_UNSUPPORTED for a shape
  * that is not served.  icap_engine_fused_vocab reports the current choice.  No
  * counterpart in the reference. */

@@ -86,15 +86,24 @@ TIE_BAR = 2e-6          # about 30 fp32 ulps of a score
 
 def following_chooser(tr_ids, tr_parents, V, bar=TIE_BAR):
     """choose_successors_fn for the oracle loop + the report it fills: `ties` = (step, image,
-    rank, relative gap) per adopted pick, `failures` = the same for picks that are no near-tie."""
-    report = {"ties": [], "failures": []}
+    rank, relative gap) per adopted pick, `failures` = the same for picks that are no near-tie,
+    `min_margin` = the smallest relative gap between neighbours among the oracle's best k+1
+    candidates over all steps and images (how far the closest decision was from a tie)."""
+    report = {"ties": [], "failures": [], "min_margin": np.inf}
     step = [0]
 
     def choose(scores_flat, k):
         t = step[0]
         step[0] += 1
-        vals, idx = co.choose_top_k(scores_flat, k)
-        vals, idx = vals.copy(), idx.copy()
+        vals1, idx1 = co.choose_top_k(scores_flat, min(k + 1, scores_flat.shape[-1]))
+        s = vals1.astype(np.float64)
+        ok = s > -1e30
+        with np.errstate(invalid="ignore", over="ignore"):
+            gaps = np.abs(np.diff(s, axis=1)) / np.maximum(np.abs(s[:, :-1]), 1e-30)
+        gaps = np.where(ok[:, 1:] & ok[:, :-1], gaps, np.inf)
+        if gaps.size:
+            report["min_margin"] = min(report["min_margin"], float(gaps.min()))
+        vals, idx = vals1[:, :k].copy(), idx1[:, :k].copy()
         idx_g = tr_parents[t].astype(np.int64) * V + tr_ids[t].astype(np.int64)
         for b in np.nonzero((idx != idx_g).any(axis=1))[0]:
             in_range = (idx_g[b] >= 0).all() and (idx_g[b] < scores_flat.shape[1]).all()
@@ -117,7 +126,7 @@ def following_chooser(tr_ids, tr_parents, V, bar=TIE_BAR):
 
 
 def check_decode_following(p, img, W, T, start_id, eos_id, lpw, tile_mode, tok_g, tr_g, cell="lstm",
-                           bar=TIE_BAR, rtol=1e-5, oracle_fn=None):
+                           bar=TIE_BAR, rtol=1e-5, oracle_fn=None, return_report=False):
     """Runs the oracle loop following the engine's records (tr_g: ids, parents, scores,
     log_probs as numpy [T,B,W]; tok_g [B,T]) and asserts the whole-sequence parity bar.
     Returns (images that needed at least one near-tie adoption, the adopted ties)."""
@@ -163,4 +172,6 @@ def check_decode_following(p, img, W, T, start_id, eos_id, lpw, tile_mode, tok_g
         assert match, "image %d: returned caption is not the best beam's path (nor a tied one)" % b
         final_ties.append((T, int(b), -1, 0.0))
     tied_images = sorted({b for _, b, _, _ in report["ties"] + final_ties})
+    if return_report:
+        return len(tied_images), report["ties"] + final_ties, report
     return len(tied_images), report["ties"] + final_ties

@@ -347,13 +347,20 @@ def test_fused_and_unfused_vocab_paths_agree():
     for k in ("best", "scores", "lp"):
         np.testing.assert_allclose(np.maximum(a[k], -1e30), np.maximum(b[k], -1e30), rtol=3e-6,
                                    err_msg=k)
-    # a beam wider than 5 is served by the unfused kernels only
+    # a beam wider than 5: fused in exact-f32 mode (records of 5 + the proof-or-repeat beam
+    # step, tests/test_gpu_wide.py), unfused kernels only with bf16 operands
     cfg8 = CaptionConfig(B=2, W=8, L=16, F=128, D=64, E=64, H=64, U=64, V=1000, T=3, start_id=3,
                          eos_id=4)
+    eng8 = CaptionEngine(cfg8, {k: to_dev(v) for k, v in p.items()})
+    eng8.set_fused_vocab(True)
+    assert eng8.fused_vocab
+    eng8.close()
+    cfg8.precision = "bf16"
     eng8 = CaptionEngine(cfg8, {k: to_dev(v) for k, v in p.items()})
     assert not eng8.fused_vocab
     with pytest.raises(RuntimeError):
         eng8.set_fused_vocab(True)
+    eng8.close()
 
 
 PROD = dict(F=2048, D=256, E=256, H=512, V=10000)
@@ -373,15 +380,42 @@ def test_decode_full_size_config2_flat_weights_tie_stress():
     assert nbad <= 40, explained          # observed: 23
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split"])
 @pytest.mark.parametrize("tile_mode", ["reference", "repeat"])
-def test_decode_full_size_config2_peaked_weights_exact(tile_mode):
-    """The headline configuration at full size on weights with peaked word distributions
-    (logit spread about 5, captions that differ per image, the end token reached at every
-    length): the engine's tokens and all its beam records equal the free-running oracle's,
-    with ZERO near-tie adoptions, and log-probs / scores agree to 1e-5."""
-    nbad, explained = _compare_decode({}, PROD, seed=0, B=512, L=64, T=20, W=3, tile_mode=tile_mode,
-                                      peaked=True)
-    assert nbad == 0, explained
+def test_decode_full_size_config2_exact_tokens(tile_mode, precision):
+    """The headline configuration at full size (512 images, beam 3, 20 steps, V = 10000) with
+    NO tie rule: weights with peaked word distributions (captions differ per image, the end
+    token is reached at every length) and the margin-screened image batch of
+    tests/golden/peaked_batch_seeds.json, on which every top-k decision of the oracle is at
+    least 3e-5 (relative) clear of the next candidate - ten times the fp32 noise between two
+    summation orders.  The engine's tokens and all 512 x 20 x 3 beam records must equal the
+    free-running oracle's, log-probs and scores to 1e-5.  The margin is re-measured here."""
+    import json
+    import os
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    with open(os.path.join(os.path.dirname(__file__), "golden", "peaked_batch_seeds.json")) as f:
+        fx = json.load(f)
+    B, W, T, L = fx["B"], fx["W"], fx["T"], fx["L"]
+    assert (B, W, T, L, fx["dims"]) == (512, 3, 20, 64, PROD)
+    p = co.make_peaked_params(fx["param_seed"], **PROD)
+    img = np.concatenate([co.make_images(s, 1, L, PROD["F"]) for s in fx["image_seeds"]], axis=0)
+    cfg = CaptionConfig(B=B, W=W, L=L, F=PROD["F"], D=PROD["D"], E=PROD["E"], H=PROD["H"],
+                        U=PROD["H"], V=PROD["V"], T=T, start_id=3, eos_id=4, tile_mode=tile_mode,
+                        precision=precision)
+    eng = CaptionEngine(cfg, p, device=dev())
+    assert eng.fused_vocab
+    tok_g, _ = eng.decode(to_dev(img))
+    tr_g = {k: np_of(v) for k, v in eng.trace().items()}
+    tok_g = np_of(tok_g)
+    eng.close()
+    nbad, ties, report = check_decode_following(p, img, W, T, 3, 4, 1.0, tile_mode, tok_g, tr_g,
+                                                return_report=True)
+    assert nbad == 0 and not ties, ties            # the oracle ran free: nothing was adopted
+    assert report["min_margin"] >= 3e-5, report["min_margin"]
+    # the batch is a real test of the beam logic: varied captions, every length occurs
+    lens = np.array([(np.nonzero(r == 4)[0][0] if (r == 4).any() else T) for r in tok_g])
+    assert len({tuple(r) for r in tok_g.tolist()}) > 400
+    assert len(np.unique(lens)) >= 15 and (lens < T).sum() > 100
 
 
 def test_decode_full_size_is_permutation_equivariant():

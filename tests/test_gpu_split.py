@@ -110,16 +110,13 @@ def test_engine_split_small_against_oracle():
 def test_engine_split_full_size_config2_against_oracle():
     """The headline configuration in split mode against the fp32 oracle, at the fp32 bars:
     the oracle follows the engine's records, every differing pick a proven near-tie at its rank
-    (2e-6), log-probs and scores of all images within 1e-5; on the peaked weights no near-tie
-    adoption at all."""
+    (2e-6), log-probs and scores of all images within 1e-5.  (The exact-token run on the
+    margin-screened batch is tests/test_gpu_e2e.py::test_decode_full_size_config2_exact_tokens.)"""
     nbad, explained = _compare_decode({"precision": "fp32_split"}, PROD, seed=0, B=512, L=64, T=20,
                                       W=3, tile_mode="reference")
     print("split mode, full size, flat weights: %d of 512 images took a near-tie adoption"
           % nbad)
     assert nbad <= 51, explained
-    nbad, explained = _compare_decode({"precision": "fp32_split"}, PROD, seed=0, B=512, L=64, T=20,
-                                      W=3, tile_mode="reference", peaked=True)
-    assert nbad == 0, explained
 
 
 def test_engine_split_rejects_unaligned_dims():
