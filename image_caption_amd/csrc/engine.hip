@@ -65,6 +65,11 @@ int lstm_step_split(const float*, const float*, const float*, const void*, const
 bool dense_topk_bf16_supported(const float*, int, int, int, int);
 int dense_topk_bf16(const float*, const void*, const float*, int, int, int, int, int, float*, float*,
                     const LogitMasks*, hipStream_t);
+int dense_bf16_dual(const float*, const void*, const float*, float*, void*, int, int, int, int, int,
+                    hipStream_t);
+bool dense_topk_bf16_a16_blocked(int, int, int, int);
+int dense_topk_bf16_a16(const void*, int, const void*, const float*, int, int, int, int, int, float*,
+                        float*, const LogitMasks*, hipStream_t);
 int beam_step_from_records_f32(const float*, const float*, int, int, const float*, const uint8_t*,
                                const int32_t*, int, int, double, float*, int32_t*, int32_t*, float*,
                                uint8_t*, int32_t*, int, int, int, hipStream_t, int compact_first = 0);
@@ -135,6 +140,7 @@ struct icap_engine {
   // workspace views
   float *features, *pf, *pooled, *init_h, *init_c;
   float *h[2], *c, *q, *ctx, *fc1o, *logits;
+  uint16_t* fc1o16 = nullptr;  // bf16 mode: fc1's output rounded to bf16, the projection's A operand
   float *lp, *hist_scores, *hist_lp;
   int32_t *len, *hist_ids, *hist_parents, *start_ids;
   int32_t* row_len = nullptr;  // [N] target length of every beam row (baseline searcher)
@@ -162,6 +168,7 @@ struct icap_engine {
   uint8_t* fin2 = nullptr;
   int32_t* len2 = nullptr;
   long wide_rescues_forced = 0;  // test hook: raise the flag at every step
+  bool a16 = true;               // bf16 mode: bf16 hand-over between fc1 and the projection (ICAP_BF16_A16=0: off)
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr, ev_gate = nullptr;
@@ -490,10 +497,18 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           len, c.B, c.W, c.V, s, 1));
       continue;
     }
+    // bf16 mode, fused projection: fc1 also writes its output as bf16 and the projection reads
+    // that (the values the projection's own staging conversion would produce)
+    const bool a16 = topk != 0 && c.precision == ICAP_PRECISION_BF16 && e->a16;
+    const int a16_blocked = a16 && dense_topk_bf16_a16_blocked(N, c.H, c.V, topk) ? 1 : 0;
     {  // K7: fc1
       Timed tm(e, ICAP_K_FC1, s);
-      ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
-                            c.H, c.H, ICAP_ACT_NONE, s));
+      if (a16)
+        ICAP_TRY(dense_bf16_dual(e->h[cur], e->pk[icap_engine::PK_FC1], w.fc1_bias, e->fc1o, e->fc1o16,
+                                 a16_blocked, N, c.H, c.H, ICAP_ACT_NONE, s));
+      else
+        ICAP_TRY(engine_dense(e, icap_engine::PK_FC1, e->h[cur], w.fc1_kernel, w.fc1_bias, e->fc1o, N,
+                              c.H, c.H, ICAP_ACT_NONE, s));
     }
     if (topk) {
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
@@ -501,7 +516,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         ICAP_HIP(hipEventRecord(e->ev_gate, s));
       {
         Timed tm(e, ICAP_K_VOCAB, s);
-        if (c.precision == ICAP_PRECISION_BF16)
+        if (a16)
+          ICAP_TRY(dense_topk_bf16_a16(e->fc1o16, a16_blocked, e->pk[icap_engine::PK_FC2], w.fc2_bias,
+                                       N, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk, s));
+        else if (c.precision == ICAP_PRECISION_BF16)
           ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
                                    c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (c.precision == ICAP_PRECISION_F32_SPLIT)
@@ -850,6 +868,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
   const size_t o_rl = cv.take<int32_t>(N);
   const size_t o_fin2 = cv.take<uint8_t>(N), o_len2 = cv.take<int32_t>(N), o_flags = cv.take<char>(256);
+  const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
+      cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
   const bool gru = c.cell == ICAP_CELL_GRU;
   const size_t o_gk = cv.take<float>(gru ? (size_t)(c.D + c.E) * 4 * c.H : 0),
                o_gr = cv.take<float>(gru ? (size_t)c.H * 4 * c.H : 0),
@@ -971,6 +991,11 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->fin2 = (uint8_t*)(b + o_fin2);
   e->len2 = (int32_t*)(b + o_len2);
   e->flags = (int*)(b + o_flags);
+  e->fc1o16 = (uint16_t*)(b + o_fc116);
+  {
+    const char* a16_env = getenv("ICAP_BF16_A16");  // tuning knob, read per engine
+    e->a16 = !(a16_env && a16_env[0] == '0');
+  }
   if (gru) {
     e->gru_k4 = (float*)(b + o_gk);
     e->gru_r4 = (float*)(b + o_gr);

@@ -12,6 +12,8 @@
 // loads of stage k+1 in flight during the MFMAs of stage k, one barrier per stage.  LDS
 // rows are 144 bytes (128 of data + 16 pad) so that the 16-byte operand reads of 8
 // consecutive lanes fall in 8 distinct bank groups.
+#include <stdlib.h>
+
 #include "icap_common.h"
 #include "topk_epilogue.h"
 
@@ -48,16 +50,26 @@ struct Bf16Args {
   float* eos_x;
   int eos;
   LogitMasks masks;  // additive masks applied before the records are built (default: none)
+  // A already in bf16 ([M][K], row stride lda16 elements; A16 kernels) / a bf16 copy of y
+  const uint16_t* a16 = nullptr;
+  int lda16 = 0;
+  uint16_t* y16 = nullptr;  // [M][N], written beside y when not null
+  int y16_blocked = 0;      // y16 in the operand-block layout of vocab_bf16.hip instead of row-major
 };
 
-template <int BM, bool LSTM, int TOPK = 0>
+// A16: the A operand is already bf16 in memory (written by the producing kernel's epilogue,
+// same round-to-nearest-even as the staging conversion, so the products are the same): half
+// the operand traffic, and at the vocab projection's shape the 2.6 MB activation panel then
+// stays in an XCD's L2 beside its band of weight panels.
+template <int BM, bool LSTM, int TOPK = 0, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   constexpr int NT = 256;
   constexpr int WTM = BM / 2;    // wave tile rows
   constexpr int TM = WTM / 32;   // accumulators along m
   constexpr int TN = 2;          // wave tile = WTM x 64
-  constexpr int A_LD = BM * (BK / 4) / NT;  // float4 loads per thread per stage
+  constexpr int A_LD = A16 ? BM * (BK / 8) / NT : BM * (BK / 4) / NT;  // 16-byte loads per thread per stage
   constexpr int B_LD = BN * (BK / 8) / NT;  // 16-byte loads per thread per stage
+  static_assert(!A16 || !LSTM, "the bf16 A operand is built for the plain products");
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int T_LD = 68;  // floats per row of a wave's transposition patch (top-k epilogue)
@@ -78,8 +90,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   const int b_ch = tid & 7, b_r = tid >> 3;   // 32 rows per pass
   int a_row[A_LD];
 #pragma unroll
-  for (int i = 0; i < A_LD; ++i) a_row[i] = min(m0 + a_r + 16 * i, p.M - 1);  // clamped, stores are masked
-  float4 ra[A_LD];
+  for (int i = 0; i < A_LD; ++i)  // clamped, stores are masked
+    a_row[i] = A16 ? min(m0 + b_r + 32 * i, p.M - 1) : min(m0 + a_r + 16 * i, p.M - 1);
+  float4 ra[A_LD];  // (A16: the same 16 bytes hold 8 bf16)
   uint4 rb[B_LD];
   // (macros, not lambdas: arrays captured by a lambda are not split into registers)
 #define ICAP_BF16_LOAD(KT)                                                                         \
@@ -89,8 +102,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     const float* base_ = seg0_ ? p.a0 : p.a1;                                                      \
     const int ld_ = seg0_ ? p.lda0 : p.lda1;                                                       \
     const int kk_ = (seg0_ ? k0_ : k0_ - p.K0) + a_c4 * 4;                                         \
-    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] =                                       \
-        *reinterpret_cast<const float4*>(base_ + (size_t)a_row[i] * ld_ + kk_);                    \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] = A16                                   \
+        ? *reinterpret_cast<const float4*>(p.a16 + (size_t)a_row[i] * p.lda16 + k0_ + b_ch * 8)    \
+        : *reinterpret_cast<const float4*>(base_ + (size_t)a_row[i] * ld_ + kk_);                  \
     _Pragma("unroll") for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const uint4*>(      \
         p.w + (size_t)(n0 + b_r + 32 * j) * p.K + k0_ + b_ch * 8);                                 \
   }
@@ -99,10 +113,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     char* as_ = smem + (BUF) * STAGE;                                                              \
     char* bs_ = as_ + A_BYTES;                                                                     \
     _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                             \
-      bf16x4 v_;                                                                                   \
-      v_[0] = (__bf16)ra[i].x; v_[1] = (__bf16)ra[i].y;                                            \
-      v_[2] = (__bf16)ra[i].z; v_[3] = (__bf16)ra[i].w;                                            \
-      *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_c4 * 8) = v_;                    \
+      if (A16) {                                                                                   \
+        *reinterpret_cast<float4*>(as_ + (b_r + 32 * i) * ROW_B + b_ch * 16) = ra[i];              \
+      } else {                                                                                     \
+        bf16x4 v_;                                                                                 \
+        v_[0] = (__bf16)ra[i].x; v_[1] = (__bf16)ra[i].y;                                          \
+        v_[2] = (__bf16)ra[i].z; v_[3] = (__bf16)ra[i].w;                                          \
+        *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_c4 * 8) = v_;                  \
+      }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                               \
         *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_ch * 16) = rb[j];               \
@@ -201,7 +219,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
           const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = acc[i][j][r] + bv;
           if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
-          if (n_ok && m < p.M) p.y[(size_t)m * p.N + n] = v;
+          if (n_ok && m < p.M) {
+            p.y[(size_t)m * p.N + n] = v;
+            if (p.y16) {
+              // blocked: [m/32][n/16][(n%16)/8][m%32][n%8] - a wave's MFMA A operand for a k-step
+              // of 16 is then one contiguous kilobyte
+              const size_t o = p.y16_blocked
+                  ? ((((size_t)(m >> 5) * (p.N >> 4) + (n >> 4)) * 2 + ((n >> 3) & 1)) * 32 + (m & 31)) * 8 + (n & 7)
+                  : (size_t)m * p.N + n;
+              p.y16[o] = __builtin_bit_cast(uint16_t, (__bf16)v);
+            }
+          }
         }
     }
   } else {
@@ -319,6 +347,24 @@ int dense_bf16(const float* x, const void* packed_w, const float* bias, float* y
   return launch<64, false>(a, s, "gemm_bf16_kernel<64>");
 }
 
+// dense_bf16 that also writes its result rounded to bf16 ([M][N]): the A operand of a
+// following dense_topk_bf16_a16.
+int dense_bf16_dual(const float* x, const void* packed_w, const float* bias, float* y, void* y16,
+                    int y16_blocked, int M, int K, int N, int act, hipStream_t s) {
+  ICAP_REQUIRE(!y16_blocked || N % 16 == 0, "dense_bf16_dual: the blocked layout needs N %% 16 == 0");
+  ICAP_REQUIRE(x && packed_w && y && y16, "dense_bf16_dual: null pointer");
+  ICAP_REQUIRE(M > 0 && K > 0 && N > 0 && K % BK == 0, "dense_bf16_dual: bad shape M=%d K=%d N=%d", M, K, N);
+  ICAP_REQUIRE(aligned16(x) && aligned16(packed_w), "dense_bf16_dual: operands must be 16-byte aligned");
+  Bf16Args a = {};
+  a.a0 = x; a.a1 = nullptr; a.K0 = K; a.lda0 = K; a.lda1 = 0;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = y; a.M = M; a.N = N; a.K = K; a.act = act;
+  a.y16 = static_cast<uint16_t*>(y16);
+  a.y16_blocked = y16_blocked;
+  if ((long long)ceil_div(M, 128) * ceil_div(N, BN) >= 256) return launch<128, false>(a, s, "gemm_bf16_kernel<128>");
+  return launch<64, false>(a, s, "gemm_bf16_kernel<64>");
+}
+
 bool dense_topk_bf16_supported(const float* x, int M, int K, int N, int top_k) {
   return (top_k == 1 || top_k == 3 || top_k == 5) && M > 0 && K > 0 && N > 0 && K % BK == 0 &&
          aligned16(x);
@@ -346,6 +392,64 @@ int dense_topk_bf16(const float* x, const void* packed_w, const float* bias, int
   else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5>), grid, block, 0, s, a);
   ICAP_LAUNCH_CHECK("gemm_bf16_kernel<topk>");
+  return ICAP_OK;
+}
+
+bool vocab_bf16_resident_supported(int M, int K, int N, int top_k);
+int vocab_bf16_resident(const void*, const void*, const float*, int, int, int, int, int, float*, float*,
+                        const LogitMasks*, int, hipStream_t);
+
+// dense_topk_bf16 on an activation matrix that is already bf16 (from dense_bf16_dual): same
+// records.  blocked: x16 in the operand-block layout, taken by the kernel with the weight
+// panel resident in LDS (vocab_bf16.hip; served for K = 256 or 512, see
+// dense_topk_bf16_a16_blocked; opt-in with ICAP_BF16_RESIDENT=1: alone it is a little faster
+// than the staged tiles, beside the side-stream attention it is slower, because its one
+// workgroup per CU with 128 KB of LDS leaves that kernel nowhere to run);
+// otherwise x16 is row-major [M][K].
+bool dense_topk_bf16_a16_blocked(int M, int K, int N, int top_k) {
+  const char* res_env = getenv("ICAP_BF16_RESIDENT");  // (read per call: a test switches it)
+  return res_env && res_env[0] == '1' && vocab_bf16_resident_supported(M, K, N, top_k);
+}
+
+int dense_topk_bf16_a16(const void* x16, int blocked, const void* packed_w, const float* bias, int M,
+                        int K, int N, int eos, int top_k, float* records, float* eos_logit,
+                        const LogitMasks* masks, hipStream_t s) {
+  ICAP_REQUIRE(x16 && packed_w && records && eos_logit, "dense_topk_bf16_a16: null pointer");
+  ICAP_REQUIRE((top_k == 1 || top_k == 3 || top_k == 5) && M > 0 && N > 0 && K > 0 && K % BK == 0,
+               "dense_topk_bf16_a16: needs top_k in {1,3,5} and K %% 64 == 0 (M=%d K=%d N=%d top_k=%d)",
+               M, K, N, top_k);
+  ICAP_REQUIRE(aligned16(x16) && aligned16(packed_w) && aligned16(records),
+               "dense_topk_bf16_a16: unaligned buffer");
+  ICAP_REQUIRE(!blocked || vocab_bf16_resident_supported(M, K, N, top_k),
+               "dense_topk_bf16_a16: the blocked activation layout is the resident kernel's");
+  {
+    if (blocked) {
+      static int cus = 0;  // compute units of the device (the first caller's; one GPU model per process)
+      if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+          cus = n;
+        else
+          cus = 256;
+      }
+      return vocab_bf16_resident(x16, packed_w, bias, M, K, N, eos, top_k, records, eos_logit, masks,
+                                 cus, s);
+    }
+  }
+  Bf16Args a = {};
+  a.a16 = static_cast<const uint16_t*>(x16); a.lda16 = K; a.K0 = K;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = nullptr; a.M = M; a.N = N; a.K = K; a.act = ICAP_ACT_NONE;
+  a.rec = records; a.eos_x = eos_logit; a.eos = eos;
+  if (masks) a.masks = *masks;
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, BN);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1, true>), grid, block, 0, s, a);
+  else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5, true>), grid, block, 0, s, a);
+  ICAP_LAUNCH_CHECK("gemm_bf16_kernel<topk,a16>");
   return ICAP_OK;
 }
 

@@ -177,3 +177,18 @@ def test_engine_bf16_fused_and_unfused_vocab_paths_agree():
         else:
             np.testing.assert_array_equal(a, b)
     np.testing.assert_allclose(np.maximum(outs[0][4], -1e30), np.maximum(outs[1][4], -1e30), rtol=3e-6)
+
+
+def test_engine_bf16_resident_panel_kernel_agrees_with_staged_tiles(monkeypatch):
+    """The opt-in projection kernel with the weight panel resident in LDS (H = 256 or 512)
+    sums each logit in the same order as the staged-tile kernel: same successors, scores to
+    rounding of the soft-max sums."""
+    dims = (16, 128, 64, 64, 256, 3000)
+    monkeypatch.setenv("ICAP_BF16_RESIDENT", "0")
+    _, _, t0, b0, tr0 = _decode_pair(40, 3, 8, dims, 5, "bf16")
+    monkeypatch.setenv("ICAP_BF16_RESIDENT", "1")
+    _, _, t1, b1, tr1 = _decode_pair(40, 3, 8, dims, 5, "bf16")
+    np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_array_equal(tr0["ids"], tr1["ids"])
+    np.testing.assert_array_equal(tr0["parents"], tr1["parents"])
+    np.testing.assert_allclose(b0, b1, rtol=3e-6)
