@@ -65,10 +65,10 @@ PEAK_HBM_GBS = 8000.0
 
 def measured_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r*/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3
+    (profiles/r*/traffic*.json: 2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3
     runs of this same command); None when no profile of this workload is present."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
