@@ -78,6 +78,13 @@ int dense_f32_strided(const float*, int, const float*, const float*, float*, int
 int dense_topk_f32_strided(const float*, int, const float*, const float*, int, int, int, int, int,
                            float*, float*, const LogitMasks*, hipStream_t);
 bool dense_topk_attention_supported(int R, int L, int U, int D, int H, int top_k);
+bool dense_topk_beam_supported(int M, int W, int half_tiles, int top_k, int time, int compact_first);
+int dense_topk_beam_f32(const float*, int, const float*, const float*, int, int, int, int, int, float*,
+                        float*, const float*, const uint8_t*, const int32_t*, int, double, float*,
+                        int32_t*, int32_t*, float*, uint8_t*, int32_t*, int, int, int, unsigned*,
+                        unsigned, int*, hipStream_t);
+int backtrack_guarded(const int32_t*, const int32_t*, const float*, const uint8_t*, int32_t*, int32_t*,
+                      float*, int, int, int, const int*, hipStream_t);
 int dense_topk_attention_f32(const float*, int, const float*, const float*, int, int, int, int, int,
                              float*, float*, const LogitMasks*, const float*, const float*,
                              const float*, float, const float*, const float*, float, const float*,
@@ -165,6 +172,10 @@ struct icap_engine {
   // unless the flag is up.  The step then needs the state it started from: fin / len ping-pong.
   bool wide = false;
   int* flags = nullptr;        // two words (step parity), in a 256-byte block of their own
+  // exact-f32 fused path: the beam step rides in the projection's launch (dense_topk_beam_f32)
+  bool beam_in_launch = false;
+  unsigned* tile_rows_done = nullptr;  // two runs of counters (time-0 launch, the others) + error word
+  int tile_rows = 0;
   uint8_t* fin2 = nullptr;
   int32_t* len2 = nullptr;
   long wide_rescues_forced = 0;  // test hook: raise the flag at every step
@@ -339,6 +350,15 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     ICAP_HIP(hipMemsetAsync(e->fin, 0, N, s));
     if (wide) ICAP_HIP(hipMemsetAsync(e->flags, 0, 256, s));
   }
+  // The beam step inside the projection's launch: exact-f32 fused path without logit masks
+  const bool beam_in_launch = e->beam_in_launch && topk != 0 && !wide && !masks.any() &&
+                              !(e->merged && e->overlap);
+  unsigned* done0 = e->tile_rows_done;
+  unsigned* done1 = e->tile_rows_done + e->tile_rows;
+  int* beam_err = reinterpret_cast<int*>(e->tile_rows_done + 2 * e->tile_rows);
+  unsigned launches1 = 0;
+  if (beam_in_launch)
+    ICAP_HIP(hipMemsetAsync(e->tile_rows_done, 0, sizeof(unsigned) * (2 * e->tile_rows + 1), s));
 
   const int stride_g = c.tile_mode == ICAP_TILE_REPEAT ? c.W : 1;
   const int stride_k = c.tile_mode == ICAP_TILE_REPEAT ? 1 : c.B;
@@ -459,6 +479,16 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         ICAP_TRY(dense_f32_strided(e->h[cur], c.W * c.H, w.fc1_kernel, w.fc1_bias, e->fc1o, c.B, c.H,
                                    c.H, ICAP_ACT_NONE, s));
       }
+      if (beam_in_launch) {
+        Timed tm(e, ICAP_K_VOCAB, s);
+        ICAP_TRY(dense_topk_beam_f32(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V, c.eos_id,
+                                     topk, e->rec, e->eos_x, lp_in, fin, len, 0,
+                                     c.length_penalty_weight, e->hist_scores, e->hist_ids,
+                                     e->hist_parents, e->hist_lp, fin, len, c.B, c.W, 1, done0, 1,
+                                     beam_err, s));
+        if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
+        continue;
+      }
       {
         Timed tm(e, ICAP_K_VOCAB, s);
         if (merged && t + 1 < c.T)
@@ -514,6 +544,17 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       // K8+K9 fused: the projection keeps per-row top-k records, the logits never reach HBM
       if (t + 1 < c.T && side && vocab_gate && !((e->timing >> ICAP_K_VOCAB) & 1u))
         ICAP_HIP(hipEventRecord(e->ev_gate, s));
+      if (beam_in_launch && c.precision == ICAP_PRECISION_FP32) {
+        Timed tm(e, ICAP_K_VOCAB, s);
+        ICAP_TRY(dense_topk_beam_f32(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
+                                     topk, e->rec, e->eos_x, lp_in, fin, len, bs_time,
+                                     c.length_penalty_weight, e->hist_scores + (size_t)t * N,
+                                     e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
+                                     e->hist_lp + (size_t)t * N, fin, len, c.B, c.W, 0, done1,
+                                     ++launches1, beam_err, s));
+        if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
+        continue;
+      }
       {
         Timed tm(e, ICAP_K_VOCAB, s);
         if (a16)
@@ -582,8 +623,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   }
   {  // K10
     Timed tm(e, ICAP_K_BACKTRACK, s);
-    ICAP_TRY(backtrack(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N, fin,
-                       tokens, nullptr, best_score, c.T, c.B, c.W, s));
+    // (a beam step inside a projection launch that could not be taken invalidates the result)
+    ICAP_TRY(backtrack_guarded(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N,
+                               fin, tokens, nullptr, best_score, c.T, c.B, c.W,
+                               beam_in_launch ? beam_err : nullptr, s));
   }
   return ICAP_OK;
 }
@@ -868,6 +911,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
   const size_t o_rl = cv.take<int32_t>(N);
   const size_t o_fin2 = cv.take<uint8_t>(N), o_len2 = cv.take<int32_t>(N), o_flags = cv.take<char>(256);
+  e->tile_rows = ceil_div((int)N, 128);
+  const size_t o_trd = cv.take<unsigned>(2 * e->tile_rows + 1);
   const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
       cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
   const bool gru = c.cell == ICAP_CELL_GRU;
@@ -991,6 +1036,16 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->fin2 = (uint8_t*)(b + o_fin2);
   e->len2 = (int32_t*)(b + o_len2);
   e->flags = (int*)(b + o_flags);
+  e->tile_rows_done = (unsigned*)(b + o_trd);
+  {
+    // opt-in (ICAP_BEAM_IN_LAUNCH=1, read per engine): measured 7 % slower than the separate
+    // beam-records kernel at the headline shape
+    const char* bil_env = getenv("ICAP_BEAM_IN_LAUNCH");
+    e->beam_in_launch =
+        bil_env && bil_env[0] == '1' && c.precision == ICAP_PRECISION_FP32 && !e->wide &&
+        e->topk_able != 0 &&
+        dense_topk_beam_supported((int)N, c.W, dense_topk_half_tiles(c.V), e->topk_able, 1, 0);
+  }
   e->fc1o16 = (uint16_t*)(b + o_fc116);
   {
     const char* a16_env = getenv("ICAP_BF16_A16");  // tuning knob, read per engine

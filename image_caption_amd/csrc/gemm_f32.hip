@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "attention_body.h"
+#include "beam_records_body.h"
 #include "icap_common.h"
 #include "topk_epilogue.h"
 
@@ -245,9 +246,10 @@ struct FastLds {
 
 // The work of workgroup `block` of the grid (a kernel may give its first workgroups other
 // work and pass the rest on with their index shifted down).
-template <int BM, int BN, int WM, int WN, int TOPK>
-__device__ __forceinline__ void dense_fast_body(const DenseArgs& p, int block,
-                                                typename FastLds<BM, BN, WM, WN, TOPK>::U& lds) {
+// Returns the tile row it worked on.  COH: the records are stored device-coherently.
+template <int BM, int BN, int WM, int WN, int TOPK, bool COH = false>
+__device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
+                                               typename FastLds<BM, BN, WM, WN, TOPK>::U& lds) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -443,11 +445,15 @@ __device__ __forceinline__ void dense_fast_body(const DenseArgs& p, int block,
     }
     if (p.masks.any()) apply_logit_masks<32>(x, cbase, row, p.M, p.masks);
     TopkRow<TOPK> rec = topk_scan<TOPK, 32>(x, cbase, p.eos);
-    if (rec.has_eos && row < p.M) p.eos_x[row] = rec.eos_v;
+    if (rec.has_eos && row < p.M) {
+      if constexpr (COH) __hip_atomic_store(p.eos_x + row, rec.eos_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else p.eos_x[row] = rec.eos_v;
+    }
     // 3. the two lanes of a row meet (neighbour swap inside each quad)
     rec = topk_merge_neighbour<TOPK>(rec);
-    if (part == 0 && row < p.M) topk_store<TOPK>(p.rec + ((size_t)row * n_ht + ht) * RL, rec);
+    if (part == 0 && row < p.M) topk_store<TOPK, COH>(p.rec + ((size_t)row * n_ht + ht) * RL, rec);
   }
+  return tile_m;
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, int TOPK = 0>
@@ -476,6 +482,88 @@ __global__ __launch_bounds__(512, 4)  // (min 4 waves per SIMD: two workgroups p
     return;
   }
   dense_fast_body<128, 128, 4, 2, TOPK>(p, blockIdx.x - att_blocks, lds);
+}
+
+// The vocab projection with its top-k epilogue, carrying the beam-search step that consumes
+// its records in the same launch: besides the tiles the grid holds one workgroup per image,
+// which waits until the row tiles holding the image's records are complete (a counter per
+// tile row, raised once by every tile after its records are written, with device-scope
+// stores that the step reads back with device-scope loads) and then runs the step of
+// beam_records_kernel.  What it saves is the launch of that
+// kernel behind the projection's last tile, and the images whose rows finish early are
+// stepped in the compute-unit slots that the last, partly filled round of tiles leaves idle.
+// Measured at the headline shape it loses all the same (92k against 100k captions/s): the
+// tiles of the last round end over a window of 45 us, the image workgroups that become
+// resident beside them slow them by about 12 us, and the step behind the last tile takes as
+// long as the separate kernel - so the engine uses it only on request.
+//
+// Grid layout: workgroup pid lives on XCD pid % 8 at position pid / 8.  An XCD's positions
+// are its tiles in the usual order with `chunks` runs of cb image workgroups put in front of
+// its ins[c]-th tile (image = 8 * slot + xcd); the host places a run behind the tiles it waits
+// for by a whole round of resident workgroups, so that in the normal course it never waits,
+// and the runs of the last round behind every tile.  Workgroups start in grid order on each
+// XCD, so everything a waiting workgroup needs has been started before it; should a wait
+// run out all the same (2^18 polls, about a second), the workgroup raises *err and leaves its image
+// untouched - the caller turns that into an invalid result rather than a wrong one.
+struct BeamMergeArgs {
+  unsigned* done;   // [tiles_m], counted up over the launches of a decode
+  unsigned target;  // done[tm] of a complete tile row in this launch
+  int* err;
+  int q, r;         // tiles per XCD: q, one more on the first r
+  int chunks, cb;
+  int ins[8];
+};
+
+template <int TOPK, int ITEMS>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    void dense_topk_beam_kernel(DenseArgs p, RecArgs r, BeamMergeArgs m) {
+  __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
+  __shared__ int s_ok;
+  static_assert(sizeof(RecLds<TOPK, 512>) <= sizeof(lds), "the step's LDS lives in the tile buffers");
+  const int xcd = blockIdx.x & 7;
+  int pos = blockIdx.x >> 3;
+  int slot = -1;  // image slot, or -1: the XCD's pos-th tile
+  {
+    int c = 0;
+    for (; c < m.chunks; ++c) {
+      const int start = m.ins[c] + c * m.cb;
+      if (pos < start) break;
+      if (pos < start + m.cb) { slot = c * m.cb + (pos - start); break; }
+    }
+    if (slot < 0) pos -= c * m.cb;
+  }
+  if (slot < 0) {
+    if (pos >= m.q + (xcd < m.r ? 1 : 0)) return;
+    const int tile_m = dense_fast_body<128, 128, 4, 2, TOPK, true>(p, pos * 8 + xcd, lds);
+    // The records were written through with device scope; once every wave has seen its
+    // stores acknowledged the count may go up.  No cache-wide write-back or invalidate is
+    // involved on either side (the tiles next door live on what those would throw out).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(m.done + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int b = slot * 8 + xcd;
+  if (b >= r.B) return;
+  if (threadIdx.x == 0) {
+    const int row_lo = b * r.rpi;
+    const int row_hi = row_lo + (r.time <= 0 ? 0 : r.W - 1);
+    bool ok = true;
+    for (int tm = row_lo / 128; tm <= row_hi / 128 && ok; ++tm) {
+      unsigned polls = 0;
+      while (__hip_atomic_load(m.done + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < m.target) {
+        __builtin_amdgcn_s_sleep(127);
+        if (++polls > (1u << 18)) { ok = false; break; }
+      }
+    }
+    if (!ok) *m.err = 1;
+    s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  __builtin_amdgcn_s_setprio(3);
+  beam_records_body<TOPK, ITEMS, 512, true>(r, b, *reinterpret_cast<RecLds<TOPK, 512>*>(&lds));
 }
 
 // ---------------------------------------------------------------------------------
@@ -1385,6 +1473,89 @@ int dense_topk_f32_strided(const float* x, int lda, const float* w, const float*
   else
     hipLaunchKernelGGL((dense_f32_fast_kernel<128, 128, 4, 2, 2, 5>), grid, block, 0, s, a);
   ICAP_LAUNCH_CHECK("dense_f32_fast_kernel<topk>");
+  return ICAP_OK;
+}
+
+// dense_topk_f32_strided + beam_step_from_records_f32 in one launch (dense_topk_beam_kernel).
+// done: [ceil(M/128)] device counters, zero before the first launch of a sequence; launch_no
+// counts the launches that have used them since (1, 2, ...).  err: device word, raised if the
+// step of some image could not be taken.
+bool dense_topk_beam_supported(int M, int W, int half_tiles, int top_k, int time, int compact_first) {
+  const int n_rec = (time <= 0 ? 1 : W) * half_tiles;
+  return W >= 1 && W <= top_k && n_rec <= 2 * 512 && 512 >= W * (W + 2) &&
+         (compact_first ? time <= 0 : true) && M > 0;
+}
+
+int dense_topk_beam_f32(const float* x, int lda, const float* w, const float* bias, int M, int K, int N,
+                        int eos, int top_k, float* records, float* eos_logit,
+                        const float* log_probs, const uint8_t* finished, const int32_t* lengths,
+                        int time, double length_penalty_weight, float* scores, int32_t* predicted_ids,
+                        int32_t* parent_ids, float* next_log_probs, uint8_t* next_finished,
+                        int32_t* next_lengths, int B, int W, int compact_first, unsigned* done,
+                        unsigned launch_no, int* err, hipStream_t s) {
+  ICAP_REQUIRE(x && w && records && eos_logit && done && err, "dense_topk_beam_f32: null pointer");
+  ICAP_REQUIRE(log_probs && finished && lengths && scores && predicted_ids && parent_ids &&
+                   next_log_probs && next_finished && next_lengths,
+               "dense_topk_beam_f32: null beam-state pointer");
+  ICAP_REQUIRE(lda >= K && lda % 4 == 0 && (long long)M * lda < (1LL << 31),
+               "dense_topk_beam_f32: bad row stride %d", lda);
+  ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k) && aligned16(records),
+               "dense_topk_beam_f32: projection shape not served (M=%d K=%d N=%d top_k=%d)", M, K, N,
+               top_k);
+  ICAP_REQUIRE(B > 0 && M == B * (compact_first ? 1 : W) && launch_no >= 1 &&
+                   (long long)W * N < (1LL << 31),
+               "dense_topk_beam_f32: %d rows do not belong to %d images of beam width %d", M, B, W);
+  DenseArgs a{x, w, bias, nullptr, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, 128);
+  a.band_order = 1;  // (tile rows complete one after the other on every XCD)
+  const int half_tiles = 2 * a.tiles_n;
+  ICAP_REQUIRE(dense_topk_beam_supported(M, W, half_tiles, top_k, time, compact_first),
+               "dense_topk_beam_f32: %d rows x %d records exceed one workgroup", W, half_tiles);
+  RecArgs ra;
+  ra.rec = records; ra.eos_x = eos_logit; ra.HT = half_tiles;
+  ra.rpi = compact_first ? 1 : W;
+  ra.log_probs = log_probs; ra.finished = finished; ra.lengths = lengths;
+  ra.time = time; ra.eos = eos;
+  ra.scores = scores; ra.ids = predicted_ids; ra.parents = parent_ids;
+  ra.next_lp = next_log_probs; ra.next_fin = next_finished; ra.next_len = next_lengths;
+  ra.B = B; ra.W = W; ra.V = N;
+  ra.pen = make_penalty(length_penalty_weight);
+
+  BeamMergeArgs m;
+  m.done = done;
+  m.target = launch_no * (unsigned)a.tiles_n;
+  m.err = err;
+  const int total = a.tiles_m * a.tiles_n;
+  m.q = total >> 3;
+  m.r = total & 7;
+  const int slots = ceil_div(B, 8);        // image workgroups per XCD
+  m.chunks = a.tiles_m < 8 ? a.tiles_m : 8;
+  m.cb = ceil_div(slots, m.chunks);
+  // A run goes behind the last tile row its images need by `lag` positions: the 64
+  // workgroups an XCD holds at a time (32 compute units x 2) plus the skew between the XCDs'
+  // runs of tile numbers, so that those tiles have finished when the run starts.
+  static const char* lag_env = getenv("ICAP_BEAM_LAG");
+  const int lag = lag_env ? atoi(lag_env) : 80;
+  const int pw = (a.tiles_n + 7) >> 3;
+  const int rows_per_image = compact_first ? 1 : W;
+  for (int c = 0; c < 8; ++c) {
+    long long last_image = (long long)(c + 1) * m.cb * 8 - 1;
+    if (last_image > B - 1) last_image = B - 1;
+    const int tmh = (int)(((last_image + 1) * rows_per_image - 1) / 128);
+    const int at = (tmh + 1) * pw + lag;
+    m.ins[c] = at < m.q + 1 ? at : m.q + 1;
+  }
+  const int items = ceil_div((time <= 0 ? 1 : W) * half_tiles, 512);
+  const dim3 grid(8 * (m.q + 1 + m.chunks * m.cb)), block(512);
+#define ICAP_TB_LAUNCH(K_)                                                                       \
+  if (items <= 1) hipLaunchKernelGGL((dense_topk_beam_kernel<K_, 1>), grid, block, 0, s, a, ra, m); \
+  else hipLaunchKernelGGL((dense_topk_beam_kernel<K_, 2>), grid, block, 0, s, a, ra, m);
+  if (top_k == 1) { ICAP_TB_LAUNCH(1) }
+  else if (top_k == 3) { ICAP_TB_LAUNCH(3) }
+  else { ICAP_TB_LAUNCH(5) }
+#undef ICAP_TB_LAUNCH
+  ICAP_LAUNCH_CHECK("dense_topk_beam_kernel");
   return ICAP_OK;
 }
 

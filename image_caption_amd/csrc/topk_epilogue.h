@@ -134,7 +134,7 @@ __device__ __forceinline__ TopkRow<TOPK> topk_merge_neighbour(const TopkRow<TOPK
   return r;
 }
 
-template <int TOPK>
+template <int TOPK, bool DEVICE_COHERENT = false>
 __device__ __forceinline__ void topk_store(float* dst, const TopkRow<TOPK>& r) {
   constexpr int RL = 2 + 2 * TOPK;
   float out[RL];
@@ -145,10 +145,22 @@ __device__ __forceinline__ void topk_store(float* dst, const TopkRow<TOPK>& r) {
     out[2 + k] = r.tx[k];
     out[2 + TOPK + k] = __int_as_float(r.tc[k]);
   }
-  float4* d4 = reinterpret_cast<float4*>(dst);
+  if constexpr (DEVICE_COHERENT) {
+    // written through to where every XCD sees it (no cache maintenance needed by a reader
+    // inside the same launch that loads with the same scope)
+    unsigned long long* d2 = reinterpret_cast<unsigned long long*>(dst);
 #pragma unroll
-  for (int q = 0; q < RL / 4; ++q)
-    d4[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    for (int q = 0; q < RL / 2; ++q) {
+      const unsigned long long v = (unsigned long long)__float_as_uint(out[2 * q]) |
+                                   ((unsigned long long)__float_as_uint(out[2 * q + 1]) << 32);
+      __hip_atomic_store(d2 + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int q = 0; q < RL / 4; ++q)
+      d4[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+  }
 }
 #endif
 

@@ -140,13 +140,17 @@ FUSABLE = dict(F=48, D=32, E=24, H=64, V=200)     # H % 32 == 0, V % 4 == 0: the
 
 
 @pytest.mark.parametrize("W", [1, 2, 3, 5])
-@pytest.mark.parametrize("schedule", ["side", "single_stream", "merged_launch", "side_fused_query"])
+@pytest.mark.parametrize("schedule", ["side", "single_stream", "merged_launch", "side_fused_query",
+                                      "beam_in_launch"])
 def test_decode_schedules(monkeypatch, schedule, W):
-    """The default side-stream schedule, everything on one stream, and the two opt-in forms
-    (next step's query + attention inside the vocab projection's launch; query folded into the
-    side stream's attention launch) against the oracle."""
+    """The default side-stream schedule, everything on one stream, and the opt-in forms (next
+    step's query + attention inside the vocab projection's launch; query folded into the side
+    stream's attention launch; the beam step inside the projection's launch) against the
+    oracle."""
     if schedule == "merged_launch":
         monkeypatch.setenv("ICAP_MERGED", "1")
+    if schedule == "beam_in_launch":
+        monkeypatch.setenv("ICAP_BEAM_IN_LAUNCH", "1")
     if schedule == "side_fused_query":
         monkeypatch.setenv("ICAP_SIDE_FQ", "1")
 
@@ -159,6 +163,37 @@ def test_decode_schedules(monkeypatch, schedule, W):
         nbad, _ = _compare_decode({}, FUSABLE, seed=11 + W, B=7, L=6, T=6, W=W, tile_mode=tile_mode,
                                   bias_seed=5, setup=setup)
         assert nbad == 0
+
+
+@pytest.mark.parametrize("W,V", [(3, 1000), (5, 10000)])
+def test_beam_step_inside_the_projection_launch_over_several_tile_rows(monkeypatch, W, V):
+    """ICAP_BEAM_IN_LAUNCH=1 with images spread over several 128-row tiles (their workgroups
+    wait on more than one counter) and, at V = 10000 and beam 5, two records per thread."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    dims = dict(F=48, D=32, E=24, H=64, V=V)
+    B, L, T = 150, 5, 5
+    p = _params(dims, 31 + W, 6, False)
+    img = co.make_images(81 + W, B, L, dims["F"])
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ICAP_BEAM_IN_LAUNCH", on)
+        cfg = CaptionConfig(B=B, W=W, L=L, U=dims["H"], T=T, start_id=3, eos_id=4, tile_mode="repeat",
+                            **dims)
+        eng = CaptionEngine(cfg, p, device=dev())
+        eng.set_fused_vocab(True)
+        assert eng.fused_vocab
+        tok, sc = eng.decode(to_dev(img))
+        outs.append(dict(tok=np_of(tok).copy(), sc=np_of(sc).copy(),
+                         **{k: np_of(v).copy() for k, v in eng.trace().items()}))
+        eng.close()
+    for k in outs[0]:       # same records; the log-sum-exp is folded by 512 threads instead of 256
+        if outs[0][k].dtype.kind == "f":
+            np.testing.assert_allclose(np.maximum(outs[0][k], -1e30), np.maximum(outs[1][k], -1e30),
+                                       rtol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+    tr = {k: outs[0][k] for k in ("ids", "parents", "scores", "log_probs")}
+    check_decode_following(p, img, W, T, 3, 4, 1.0, "repeat", outs[0]["tok"], tr)
 
 
 def test_kernel_timing_classes_and_sampling():
