@@ -89,6 +89,8 @@ SIGNATURES = {
     "icap_embedding_f32": ([_P, _P, _P, _I, _I, _I, _P], C.c_int),
     "icap_attention_f32": ([_P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P,
                             _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_attention_act_f32": ([_P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P,
+                                _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_lstm_step_f32": ([_P] * 12 + [_I] * 5 + [_P], C.c_int),
     "icap_gru_pack_f32": ([_P] * 6 + [_I] * 2 + [_P], C.c_int),
     "icap_gru_step_bf16": ([_P] * 7 + [_I] * 4 + [_P], C.c_int),
@@ -134,6 +136,8 @@ SIGNATURES = {
     "icap_residual_layernorm_f32": ([_P, _P, _P, _P, _P, _I, _I, _F, _P], C.c_int),
     "icap_mha_self_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_mha_cross_step_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "icap_mha_scores_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "icap_mha_combine_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "icap_tengine_create": ([_P, _P, _P], C.c_int),
     "icap_tengine_destroy": ([_P], C.c_int),
     "icap_tengine_refresh_weights": ([_P, _P], C.c_int),

@@ -17,11 +17,11 @@ constexpr int ATT_THREADS = 256;
 
 // A workgroup walks work items blockIdx.x, blockIdx.x + gridDim.x, ... (the grid may be
 // capped, see attention_f32).
-template <int RB, int UCH, bool VEC>
+template <int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH>
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.high_prio) __builtin_amdgcn_s_setprio(3);
-  attention_body<ATT_THREADS, RB, UCH, VEC>(p, smem, blockIdx.x, gridDim.x);
+  attention_body<ATT_THREADS, RB, UCH, VEC, ACT>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Query projection + attention in one launch (attention_fq_body), shaped to sit beside two
@@ -43,6 +43,31 @@ int launch_attention(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
                        smem, s, a);
   ICAP_LAUNCH_CHECK("attention_f32_kernel");
   return ICAP_OK;
+}
+
+// Other activations than tanh (module API only): one row per group.
+template <int UCH, int ACT>
+int launch_attention_act(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
+  if (vec)
+    hipLaunchKernelGGL((attention_f32_kernel<1, UCH, true, ACT>), dim3(a.grid), dim3(ATT_THREADS), smem,
+                       s, a);
+  else
+    hipLaunchKernelGGL((attention_f32_kernel<1, UCH, false, ACT>), dim3(a.grid), dim3(ATT_THREADS),
+                       smem, s, a);
+  ICAP_LAUNCH_CHECK("attention_f32_kernel<act>");
+  return ICAP_OK;
+}
+
+template <int ACT>
+int dispatch_uch_act(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
+  const int uch = ceil_div(a.U, 256);
+  switch (uch) {
+    case 1: return launch_attention_act<1, ACT>(a, vec, smem, s);
+    case 2: return launch_attention_act<2, ACT>(a, vec, smem, s);
+    case 3:
+    case 4: return launch_attention_act<4, ACT>(a, vec, smem, s);
+    default: return fail(ICAP_ERR_UNSUPPORTED, "attention_f32: U = %d exceeds 1024", a.U);
+  }
 }
 
 template <int RB>
@@ -104,12 +129,34 @@ __global__ __launch_bounds__(256) void embedding_kernel(const float* __restrict_
 // max_workgroups > 0 caps the grid: the workgroups then walk the groups in turn.  A caller
 // that runs this kernel beside a matrix kernel on another stream caps it at one workgroup
 // per compute unit, which leaves the matrix kernel its full occupancy.
+int attention_act_f32(const float* pf, const float* features, const float* q, const float* v,
+                      float bv, const float* score_bias, const float* gate_state,
+                      const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
+                      int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
+                      int activation, hipStream_t s);
+
 int attention_f32(const float* pf, const float* features, const float* q, const float* v,
                   float bv, const float* score_bias, const float* gate_state,
                   const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                   int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
                   hipStream_t s) {
+  return attention_act_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx,
+                           weights, G, R, stride_g, stride_k, L, U, D, H, max_workgroups,
+                           ICAP_ATT_ACT_TANH, s);
+}
+
+// activation: ICAP_ATT_ACT_*; anything but tanh serves one row per group (the layer called on
+// its own, attention/attention.py:40-65 with a non-default activation, :31).
+int attention_act_f32(const float* pf, const float* features, const float* q, const float* v,
+                      float bv, const float* score_bias, const float* gate_state,
+                      const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
+                      int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
+                      int activation, hipStream_t s) {
   ICAP_REQUIRE(pf && features && q && v && ctx, "attention_f32: null pointer");
+  ICAP_REQUIRE(activation >= ICAP_ATT_ACT_TANH && activation <= ICAP_ATT_ACT_SIGMOID,
+               "attention_f32: unknown activation %d", activation);
+  ICAP_REQUIRE(activation == ICAP_ATT_ACT_TANH || R == 1,
+               "attention_f32: activations other than tanh serve one row per group (got %d)", R);
   ICAP_REQUIRE(!gate_state || gate_w, "attention_f32: gate_state needs gate_w");
   ICAP_REQUIRE(G > 0 && L > 0 && U > 0 && D > 0, "attention_f32: bad shape");
   ICAP_REQUIRE(R >= 1 && R <= ATT_MAX_ROWS, "attention_f32: rows_per_group %d outside [1,%d]", R,
@@ -143,6 +190,9 @@ int attention_f32(const float* pf, const float* features, const float* q, const 
   if (max_workgroups > 0 && max_workgroups < a.grid) a.grid = max_workgroups;
   const size_t smem = sizeof(float) * attention_lds_floats(ATT_THREADS, R, rb, L, D);
   ICAP_REQUIRE(smem <= 160 * 1024, "attention_f32: L*R or D too large for LDS (%zu bytes)", smem);
+  if (activation == ICAP_ATT_ACT_LINEAR) return dispatch_uch_act<ATT_ACT_LINEAR>(a, vec, smem, s);
+  if (activation == ICAP_ATT_ACT_RELU) return dispatch_uch_act<ATT_ACT_RELU>(a, vec, smem, s);
+  if (activation == ICAP_ATT_ACT_SIGMOID) return dispatch_uch_act<ATT_ACT_SIGMOID>(a, vec, smem, s);
   switch (rb) {
     case 1: return dispatch_uch<1>(a, vec, smem, s);
     case 2: return dispatch_uch<2>(a, vec, smem, s);

@@ -63,9 +63,20 @@ inline size_t attention_lds_floats(int nt, int R, int rb, int L, int D) {
 }
 
 #if defined(__HIPCC__)
+// The activation inside the score: tanh (the reference default, attention/attention.py:31)
+// or one of the other named forms a caller may construct the layer with.
+constexpr int ATT_ACT_TANH = 0, ATT_ACT_LINEAR = 1, ATT_ACT_RELU = 2, ATT_ACT_SIGMOID = 3;
+template <int ACT>
+__device__ __forceinline__ float att_act(float x) {
+  if constexpr (ACT == ATT_ACT_LINEAR) return x;
+  else if constexpr (ACT == ATT_ACT_RELU) return fmaxf(x, 0.f);
+  else if constexpr (ACT == ATT_ACT_SIGMOID) return fast_sigmoid(x);
+  else return fast_tanh(x);
+}
+
 // RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.  The
 // workgroup (NT threads) walks work items first, first + stride, ...
-template <int NT, int RB, int UCH, bool VEC>
+template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH>
 __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int first, int stride) {
   constexpr int WAVES = NT / 64;
   float* s_w = reinterpret_cast<float*>(smem);
@@ -130,10 +141,10 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
         float a = 0.f;
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch) {
-          a += v4[ch].x * fast_tanh(x[ch].x + q4[r][ch].x);
-          a += v4[ch].y * fast_tanh(x[ch].y + q4[r][ch].y);
-          a += v4[ch].z * fast_tanh(x[ch].z + q4[r][ch].z);
-          a += v4[ch].w * fast_tanh(x[ch].w + q4[r][ch].w);
+          a += v4[ch].x * att_act<ACT>(x[ch].x + q4[r][ch].x);
+          a += v4[ch].y * att_act<ACT>(x[ch].y + q4[r][ch].y);
+          a += v4[ch].z * att_act<ACT>(x[ch].z + q4[r][ch].z);
+          a += v4[ch].w * att_act<ACT>(x[ch].w + q4[r][ch].w);
         }
         part[r] = wave_sum(a);
       }

@@ -123,19 +123,25 @@ __global__ __launch_bounds__(NT) void beam_gather_kernel(
   const int o = blockIdx.x * NT + threadIdx.x;
   if (o >= B * K) return;
   const int b = o / K;
-  long long flat = word_indices[o];
-  const long long hi = (long long)W * V - 1;
-  flat = flat < 0 ? 0 : (flat > hi ? hi : flat);  // host side rejects out-of-range choices
-  const int word = (int)(flat % V);
-  const int parent = (int)(flat / V);
-  const size_t rp = (size_t)b * W + parent;
-  const int pfin = finished[rp] ? 1 : 0;
+  // An index outside [0, W*V) is not an error here: like the gathers of the reference on a
+  // GPU (tf.gather stores 0 for an out-of-range index) it yields log-prob 0 and, where the
+  // parent beam is out of range too, an unfinished parent of length 0; word and parent are
+  // the floor quotient / remainder the reference computes from the raw index.
+  const long long flat = word_indices[o];
+  const bool in_range = flat >= 0 && flat < (long long)W * V;
+  long long parent_l = flat / V, word_l = flat % V;
+  if (word_l < 0) { word_l += V; parent_l -= 1; }
+  const int word = (int)word_l;
+  const int parent = (int)parent_l;
+  const bool parent_ok = parent_l >= 0 && parent_l < W;
+  const size_t rp = (size_t)b * W + (parent_ok ? parent : 0);
+  const int pfin = (parent_ok && finished[rp]) ? 1 : 0;
   const int nfin = (pfin || word == eos) ? 1 : 0;
   ids[o] = word;
   parents[o] = parent;
-  next_lp[o] = totals[(size_t)b * W * V + flat];
+  next_lp[o] = in_range ? totals[(size_t)b * W * V + flat] : 0.f;
   next_fin[o] = (uint8_t)nfin;
-  next_len[o] = lengths[rp] + ((word != eos && !nfin) ? 1 : 0);
+  next_len[o] = (parent_ok ? lengths[rp] : 0) + ((word != eos && !nfin) ? 1 : 0);
 }
 
 // (1 - fm) * finished_row + fm * probs with fm = 1 - finished, as floats like the reference
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(NT) void batch_gather_kernel(const float* __restric
   const int o = blockIdx.x * NT + threadIdx.x;
   if (o >= B * Y) return;
   const int b = o / Y;
-  int j = idx[o];
-  j = j < 0 ? 0 : (j >= X ? X - 1 : j);  // host side rejects out-of-range indices
-  out[o] = a[(size_t)b * X + j];
+  const int j = idx[o];
+  // (an out-of-range index stores 0, as tf.gather does on a GPU)
+  out[o] = (j >= 0 && j < X) ? a[(size_t)b * X + j] : 0.f;
 }
 
 // One thread per four consecutive logits of a row (V % 4 == 0) or per logit.

@@ -94,6 +94,9 @@ bool attention_fq_supported(int R, int L, int U, int D, int H);
 int attention_fq_f32(const float*, const float*, const float*, float, const float*, const float*,
                      float, const float*, const float*, float*, int, int, int, int, int, int, int,
                      int, int, hipStream_t);
+int attention_act_f32(const float*, const float*, const float*, const float*, float, const float*,
+                      const float*, const float*, float, float*, float*, int, int, int, int, int, int,
+                      int, int, int, int, hipStream_t);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, int, hipStream_t);
@@ -724,6 +727,16 @@ int icap_attention_f32(const float* pf, const float* features, const float* q, c
   return attention_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
                        G, rows_per_group, row_stride_g, row_stride_k, L, U, D, H, 0,
                        (hipStream_t)stream);
+}
+
+int icap_attention_act_f32(const float* pf, const float* features, const float* q, const float* v,
+                           float bv, const float* score_bias, const float* gate_state,
+                           const float* gate_w, float gate_b, float* ctx, float* weights, int G,
+                           int rows_per_group, int row_stride_g, int row_stride_k, int L, int U,
+                           int D, int H, int activation, icap_stream_t stream) {
+  return attention_act_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx,
+                           weights, G, rows_per_group, row_stride_g, row_stride_k, L, U, D, H, 0,
+                           activation, (hipStream_t)stream);
 }
 
 int icap_lstm_step_f32(const float* ctx, const float* emb, const float* table, const int32_t* ids,

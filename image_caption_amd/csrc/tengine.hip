@@ -38,6 +38,9 @@ int mha_self_step_f32(const float*, const float*, float*, int, int, int, int, in
 int add_f32(float*, const float*, long long, long long, hipStream_t);
 int mha_cross_step_f32(const float*, const float*, float*, int, int, int, int, int, int, int,
                        const float*, int, hipStream_t);
+int mha_scores_f32(const float*, const float*, const float*, float*, int, int, int, int, int, int,
+                   hipStream_t);
+int mha_combine_f32(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
 namespace {
 
@@ -323,6 +326,17 @@ int icap_mha_cross_step_f32(const float* q, const float* kv, float* out, int G, 
                             const float* mask, int mask_per_group, icap_stream_t stream) {
   return mha_cross_step_f32(q, kv, out, G, rows_per_group, row_stride_g, row_stride_k, L, heads,
                             key_dim, mask, mask_per_group, (hipStream_t)stream);
+}
+
+int icap_mha_scores_f32(const float* q, const float* k, const float* mask, float* probs, int Bf, int T,
+                        int S, int heads, int key_dim, int softmax_segment, icap_stream_t stream) {
+  return mha_scores_f32(q, k, mask, probs, Bf, T, S, heads, key_dim, softmax_segment,
+                        (hipStream_t)stream);
+}
+
+int icap_mha_combine_f32(const float* probs, const float* v, float* out, int Bf, int T, int S,
+                         int heads, int value_dim, icap_stream_t stream) {
+  return mha_combine_f32(probs, v, out, Bf, T, S, heads, value_dim, (hipStream_t)stream);
 }
 
 int icap_tengine_refresh_weights(icap_tengine* e, icap_stream_t stream) {

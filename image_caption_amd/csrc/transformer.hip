@@ -250,7 +250,102 @@ __global__ __launch_bounds__(NT) void add_kernel(float* __restrict__ x, const fl
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// ---- the general form of MultiHeadAttention._compute_attention (attention.py:476-524) ----
+// for what the step kernels above do not serve: keys and values from different tensors, a
+// value width of its own, several attention axes (flattened by the caller; the soft-max then
+// runs over the last key axis only, as the reference's Softmax(axis=-1) does, `:457-458`),
+// and the attention probabilities as an output.  Two plain kernels, one wave per output row.
+//
+// probs[b][n][t][:] = softmax per `seg` consecutive s of ((q[b][t][n][:] * scale) . k[b][s][n][:]
+//                                                        + (1 - mask[b][n][t][s]) * -1e9)
+constexpr int MHA_S_MAX = 4096;  // scores of one row staged in LDS (4 waves x 16 KB)
+
+__global__ __launch_bounds__(NT) void mha_scores_kernel(const float* __restrict__ q,
+                                                        const float* __restrict__ k,
+                                                        const float* __restrict__ mask,
+                                                        float* __restrict__ probs, int Bf, int T,
+                                                        int S, int N, int Dk, int seg, float scale) {
+  extern __shared__ float s_sc[];  // [NT / 64][S]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * (NT / 64) + wave;  // (b, n, t)
+  if (row >= (long long)Bf * N * T) return;
+  const int t = (int)(row % T);
+  const int n = (int)((row / T) % N);
+  const int b = (int)(row / ((long long)T * N));
+  const float* qr = q + (((size_t)b * T + t) * N + n) * Dk;
+  float* sc = s_sc + (size_t)wave * S;
+  for (int s = lane; s < S; s += 64) {
+    const float* kr = k + (((size_t)b * S + s) * N + n) * Dk;
+    float a = 0.f;
+    for (int d = 0; d < Dk; ++d) a += (qr[d] * scale) * kr[d];
+    if (mask) a += (1.0f - mask[(size_t)row * S + s]) * -1e9f;
+    sc[s] = a;
+  }
+  // (a wave reads back only what its own lanes wrote: no barrier, the LDS counter orders it)
+  float* pr = probs + (size_t)row * S;
+  for (int s0 = 0; s0 < S; s0 += seg) {
+    float m = -INFINITY;
+    for (int s = s0 + lane; s < s0 + seg; s += 64) m = fmaxf(m, sc[s]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int s = s0 + lane; s < s0 + seg; s += 64) {
+      const float e = expf(sc[s] - m);
+      sc[s] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int s = s0 + lane; s < s0 + seg; s += 64) pr[s] = sc[s] / sum;
+  }
+}
+
+// out[b][t][n][:] = sum_s probs[b][n][t][s] * v[b][s][n][:]
+__global__ __launch_bounds__(NT) void mha_combine_kernel(const float* __restrict__ probs,
+                                                         const float* __restrict__ v,
+                                                         float* __restrict__ out, int Bf, int T, int S,
+                                                         int N, int Dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * (NT / 64) + wave;  // (b, t, n)
+  if (row >= (long long)Bf * T * N) return;
+  const int n = (int)(row % N);
+  const int t = (int)((row / N) % T);
+  const int b = (int)(row / ((long long)N * T));
+  const float* pr = probs + (((size_t)b * N + n) * T + t) * S;
+  for (int d = lane; d < Dv; d += 64) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += pr[s] * v[(((size_t)b * S + s) * N + n) * Dv + d];
+    out[(size_t)row * Dv + d] = a;
+  }
+}
+
 }  // namespace
+
+int mha_scores_f32(const float* q, const float* k, const float* mask, float* probs, int Bf, int T,
+                   int S, int N, int Dk, int seg, hipStream_t s) {
+  ICAP_REQUIRE(q && k && probs, "mha_scores_f32: null pointer");
+  ICAP_REQUIRE(Bf > 0 && T > 0 && S > 0 && N > 0 && Dk > 0, "mha_scores_f32: bad shape");
+  ICAP_REQUIRE(seg > 0 && S % seg == 0, "mha_scores_f32: the soft-max segment %d does not divide S = %d",
+               seg, S);
+  ICAP_REQUIRE(S <= MHA_S_MAX, "mha_scores_f32: S = %d exceeds %d key positions", S, MHA_S_MAX);
+  const long long rows = (long long)Bf * N * T;
+  ICAP_REQUIRE(rows / (NT / 64) < (1LL << 31), "mha_scores_f32: too many rows");
+  const dim3 grid((unsigned)((rows + NT / 64 - 1) / (NT / 64))), block(NT);
+  hipLaunchKernelGGL(mha_scores_kernel, grid, block, sizeof(float) * (NT / 64) * S, s, q, k, mask, probs,
+                     Bf, T, S, N, Dk, seg, 1.0f / sqrtf((float)Dk));
+  ICAP_LAUNCH_CHECK("mha_scores_kernel");
+  return ICAP_OK;
+}
+
+int mha_combine_f32(const float* probs, const float* v, float* out, int Bf, int T, int S, int N, int Dv,
+                    hipStream_t s) {
+  ICAP_REQUIRE(probs && v && out, "mha_combine_f32: null pointer");
+  ICAP_REQUIRE(Bf > 0 && T > 0 && S > 0 && N > 0 && Dv > 0, "mha_combine_f32: bad shape");
+  const long long rows = (long long)Bf * T * N;
+  ICAP_REQUIRE(rows / (NT / 64) < (1LL << 31), "mha_combine_f32: too many rows");
+  const dim3 grid((unsigned)((rows + NT / 64 - 1) / (NT / 64))), block(NT);
+  hipLaunchKernelGGL(mha_combine_kernel, grid, block, 0, s, probs, v, out, Bf, T, S, N, Dv);
+  ICAP_LAUNCH_CHECK("mha_combine_kernel");
+  return ICAP_OK;
+}
 
 int embed_pos_f32(const float* table, const int32_t* ids, const float* pos_row, float* x, int N,
                   int V, int D, hipStream_t s) {

@@ -112,9 +112,13 @@ def embedding(table, ids):
     return out
 
 
+ATT_ACTIVATIONS = {"tanh": 0, "linear": 1, "relu": 2, "sigmoid": 3}
+
+
 def attention(pf, features, q, v, bv, score_bias=None, gate_state=None, gate_w=None, gate_b=0.0,
-              rows_per_group=1, row_stride_g=1, row_stride_k=0, want_weights=True):
-    """Returns (ctx[N,D], weights[N,L] or None)."""
+              rows_per_group=1, row_stride_g=1, row_stride_k=0, want_weights=True, activation="tanh"):
+    """Returns (ctx[N,D], weights[N,L] or None).  activation: the function inside the score
+    (one of ATT_ACTIVATIONS; anything but tanh serves rows_per_group = 1)."""
     G, L, U = pf.shape
     D = features.shape[-1]
     N = q.shape[0]
@@ -125,11 +129,13 @@ def attention(pf, features, q, v, bv, score_bias=None, gate_state=None, gate_w=N
     H = gate_state.shape[1] if gate_state is not None else 0
     ctx = torch.empty(N, D, dtype=f32, device=pf.device)
     weights = torch.empty(N, L, dtype=f32, device=pf.device) if want_weights else None
-    _call("icap_attention_f32", _chk(pf, f32, "pf"), _chk(features, f32, "features"),
+    if activation not in ATT_ACTIVATIONS:
+        raise ValueError("attention: activation must be one of %s" % sorted(ATT_ACTIVATIONS))
+    _call("icap_attention_act_f32", _chk(pf, f32, "pf"), _chk(features, f32, "features"),
               _chk(q, f32, "q"), _chk(v, f32, "v"), float(bv), _opt(score_bias, f32, "score_bias"),
               _opt(gate_state, f32, "gate_state"), _opt(gate_w, f32, "gate_w"), float(gate_b),
               _chk(ctx, f32, "ctx"), _opt(weights, f32, "weights"), G, rows_per_group,
-              row_stride_g, row_stride_k, L, U, D, H, current_stream())
+              row_stride_g, row_stride_k, L, U, D, H, ATT_ACTIVATIONS[activation], current_stream())
     return ctx, weights
 
 
@@ -262,6 +268,35 @@ def mha_self_step(q, kv_cache, heads, key_dim, pos, mask_mode=0):
     out = torch.empty_like(q)
     _call("icap_mha_self_step_f32", _chk(q, f32, "q"), _chk(kv_cache, f32, "kv_cache"),
               out.data_ptr(), N, int(heads), int(key_dim), int(pos), int(mask_mode), current_stream())
+    return out
+
+
+def mha_scores(q, k, mask=None, softmax_segment=None):
+    """q [Bf,T,N,Dk], k [Bf,S,N,Dk], mask None or [Bf,N,T,S] (1 = attend) -> attention
+    probabilities [Bf,N,T,S]; the soft-max runs over runs of softmax_segment key positions
+    (default: all S)."""
+    Bf, T, N, Dk = q.shape
+    S = k.shape[1]
+    if k.shape != (Bf, S, N, Dk):
+        raise ValueError("mha_scores: k must be [Bf,S,N,Dk]")
+    if mask is not None and tuple(mask.shape) != (Bf, N, T, S):
+        raise ValueError("mha_scores: mask must be [Bf,N,T,S]")
+    probs = torch.empty(Bf, N, T, S, dtype=f32, device=q.device)
+    _call("icap_mha_scores_f32", _chk(q, f32, "q"), _chk(k, f32, "k"), _opt(mask, f32, "mask"),
+          probs.data_ptr(), Bf, T, S, N, Dk, S if softmax_segment is None else int(softmax_segment),
+          current_stream())
+    return probs
+
+
+def mha_combine(probs, v):
+    """probs [Bf,N,T,S], v [Bf,S,N,Dv] -> [Bf,T,N,Dv]."""
+    Bf, N, T, S = probs.shape
+    Dv = v.shape[-1]
+    if v.shape != (Bf, S, N, Dv):
+        raise ValueError("mha_combine: v must be [Bf,S,N,Dv]")
+    out = torch.empty(Bf, T, N, Dv, dtype=f32, device=probs.device)
+    _call("icap_mha_combine_f32", _chk(probs, f32, "probs"), _chk(v, f32, "v"), out.data_ptr(), Bf, T,
+          S, N, Dv, current_stream())
     return out
 
 

@@ -102,6 +102,18 @@ int icap_attention_f32(const float* pf, const float* features, const float* q,
                        float* ctx, float* weights,
                        int G, int rows_per_group, int row_stride_g, int row_stride_k,
                        int L, int U, int D, int H, icap_stream_t stream);
+/* The same with another activation inside the score than tanh (BahdanauAttention's
+ * `activation` argument, attention/attention.py:31,47); these serve rows_per_group = 1. */
+#define ICAP_ATT_ACT_TANH 0
+#define ICAP_ATT_ACT_LINEAR 1
+#define ICAP_ATT_ACT_RELU 2
+#define ICAP_ATT_ACT_SIGMOID 3
+int icap_attention_act_f32(const float* pf, const float* features, const float* q,
+                           const float* v, float bv, const float* score_bias,
+                           const float* gate_state, const float* gate_w, float gate_b,
+                           float* ctx, float* weights,
+                           int G, int rows_per_group, int row_stride_g, int row_stride_k,
+                           int L, int U, int D, int H, int activation, icap_stream_t stream);
 
 /* One Keras LSTMCell step with the input concatenation and embedding gather fused:
  *   x = [ctx[n,:C] | emb_n],  emb_n = table[ids[n]] (ids != NULL) or emb[n] (ids == NULL)
@@ -540,6 +552,22 @@ int icap_mha_self_step_f32(const float* q, const float* kv_cache, float* out, in
 int icap_mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int rows_per_group,
                             int row_stride_g, int row_stride_k, int L, int heads, int key_dim,
                             const float* mask, int mask_per_group, icap_stream_t stream);
+
+/* The general form of MultiHeadAttention._compute_attention (attention.py:476-524), for the
+ * call forms the step kernels do not serve: key != value, value_dim != key_dim, several
+ * attention axes, return_attention_scores (attention.py:259-270,526-562).
+ * q [Bf][T][heads][key_dim], k [Bf][S][heads][key_dim] (projected, unscaled; the query is
+ * multiplied by 1/sqrt(key_dim) first, `:501`), mask NULL or [Bf][heads][T][S] (1 = attend),
+ * applied as (1 - mask) * -1e9 (`:461-474`); probs [Bf][heads][T][S].  The soft-max runs over
+ * every run of softmax_segment consecutive key positions: S for one attention axis, the size of
+ * the LAST key attention axis when several axes were flattened into S (the reference builds
+ * Softmax(axis=-1), `:457-458`).  S <= 4096. */
+int icap_mha_scores_f32(const float* q, const float* k, const float* mask, float* probs, int Bf, int T,
+                        int S, int heads, int key_dim, int softmax_segment, icap_stream_t stream);
+/* out[Bf][T][heads][value_dim] = sum_s probs[Bf][heads][T][s] * v[Bf][s][heads][value_dim]
+ * (the combine einsum, attention.py:522-523). */
+int icap_mha_combine_f32(const float* probs, const float* v, float* out, int Bf, int T, int S,
+                         int heads, int value_dim, icap_stream_t stream);
 
 typedef struct icap_tconfig {
   int32_t B, W, L, F, D;        /* images, beam width, locations, CNN feature dim, encoder dim */

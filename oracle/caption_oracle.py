@@ -98,8 +98,9 @@ def feature_proj_state(features, kernel, bias, mask=None):
     return dense(pooled, kernel, bias)
 
 
-def bahdanau_attention(features, hidden, p, bias=None, w1f=None):
-    """`BahdanauAttention.call` (`attention/attention.py:40-65`).
+def bahdanau_attention(features, hidden, p, bias=None, w1f=None, activation=np.tanh):
+    """`BahdanauAttention.call` (`attention/attention.py:40-65`); `activation` is the
+    constructor's argument (`:31,38,47`, default tanh).
 
     score = V(tanh(W1(features) + W2(hidden)[:,None,:])) (+ bias[:, :, None]);
     weights = softmax over the L axis; context = sum_L weights * features.
@@ -108,7 +109,7 @@ def bahdanau_attention(features, hidden, p, bias=None, w1f=None):
     if w1f is None:
         w1f = dense(features, p["att_W1_kernel"], p["att_W1_bias"])        # [N,L,U]
     w2h = dense(hidden[:, None, :], p["att_W2_kernel"], p["att_W2_bias"])  # [N,1,U]
-    act = np.tanh(w1f + w2h)
+    act = activation(w1f + w2h)
     score = dense(act, p["att_V_kernel"], p["att_V_bias"])                 # [N,L,1]
     if bias is not None:
         score = score + bias[..., None]
@@ -742,6 +743,79 @@ def multi_head_attention(query, value, p, prefix, heads, key_dim, attention_mask
     w = softmax(scores, axis=-1)
     out = np.einsum("acbe,aecd->abcd", w, v).reshape(B, T, heads * key_dim)
     return dense(out, p[prefix + "o_kernel"], p[prefix + "o_bias"])
+
+
+_CHR_IDX = "abcdefghijklmnopqrstuvwxyz"
+
+
+def _attention_equations(rank, attn_axes):
+    """`_build_attention_equation` (`attention/attention.py:84-125`): the einsum equations of
+    the query-key product and of the combination for projected tensors of rank `rank`
+    (batch, <dims>, heads, channels) and the given attention axes."""
+    target = _CHR_IDX[:rank]
+    batch_dims = tuple(int(i) for i in np.delete(range(rank), tuple(attn_axes) + (rank - 1,)))
+    offset = rank
+    source = ""
+    for i in range(rank):
+        if i in batch_dims or i == rank - 1:
+            source += target[i]
+        else:
+            source += _CHR_IDX[offset]
+            offset += 1
+    product = "".join([target[i] for i in batch_dims] + [target[i] for i in attn_axes] +
+                      [source[i] for i in attn_axes])
+    return "%s,%s->%s" % (source, target, product), "%s,%s->%s" % (product, source, target), len(product)
+
+
+def multi_head_attention_general(query, value, p, prefix, num_heads, key_dim, key=None, value_dim=None,
+                                 attention_axes=None, attention_mask=None, output_shape=None,
+                                 use_bias=True):
+    """`MultiHeadAttention.call` (`attention/attention.py:526-562`) with every constructor
+    option (`:259-294`): returns (attention_output, attention_scores).  Kernels are the flattened
+    EinsumDense kernels: `q/k_kernel` [Din, heads*key_dim], `v_kernel` [Din, heads*value_dim],
+    `o_kernel` [heads*value_dim, prod(output_shape)].  The soft-max is over the LAST axis of the
+    scores only (`:457-458`), also when several attention axes are given."""
+    dt = query.dtype
+    value_dim = value_dim if value_dim else key_dim
+    if key is None:
+        key = value
+
+    def proj(x, name, d):
+        b = p[prefix + name + "_bias"] if use_bias else None
+        y = np.matmul(x, p[prefix + name + "_kernel"])
+        if b is not None:
+            y = y + b
+        return y.astype(dt).reshape(x.shape[:-1] + (num_heads, d))
+
+    q = proj(query, "q", key_dim)
+    k = proj(key, "k", key_dim)
+    v = proj(value, "v", value_dim)
+    rank = q.ndim
+    if attention_axes is None:
+        attention_axes = tuple(range(1, rank - 2))                        # `:449-452`
+    elif not hasattr(attention_axes, "__len__"):
+        attention_axes = (attention_axes,)
+    attention_axes = tuple(attention_axes)
+    dot_eq, combine_eq, _ = _attention_equations(rank, attention_axes)
+    q = q * dt.type(1.0 / math.sqrt(float(key_dim)))                       # `:501`
+    scores = np.einsum(dot_eq, k, q)                                       # `:506`
+    if attention_mask is not None:                                         # `:461-474`
+        m = np.asarray(attention_mask)
+        axis = -len(attention_axes) * 2 - 1
+        for _ in range(scores.ndim - m.ndim):
+            m = np.expand_dims(m, axis=axis)
+        with np.errstate(over="ignore"):
+            scores = scores + (dt.type(1.0) - m.astype(dt)) * dt.type(-1e9)
+    scores = softmax(scores, axis=-1)
+    out = np.einsum(combine_eq, scores, v)                                 # [query dims, heads, value_dim]
+    if output_shape:
+        out_dims = tuple(output_shape) if hasattr(output_shape, "__len__") else (int(output_shape),)
+    else:
+        out_dims = (query.shape[-1],)
+    y = np.matmul(out.reshape(out.shape[:-2] + (num_heads * value_dim,)), p[prefix + "o_kernel"])
+    if use_bias:
+        y = y + p[prefix + "o_bias"]
+    return y.astype(dt).reshape(query.shape[:-1] + out_dims), scores
 
 
 def transformer_decoder_stack(p, x, encoder_outputs, n_layers, heads, key_dim,

@@ -184,3 +184,34 @@ def test_bad_arguments_raise(ops):
         ops.beam_step(torch.zeros(1, 17, 20, device=dev()), torch.zeros(1, 17, device=dev()),
                       torch.zeros(1, 17, dtype=torch.uint8, device=dev()),
                       torch.zeros(1, 17, dtype=torch.int32, device=dev()), 0, 0, 1.0)
+
+
+@pytest.mark.parametrize("activation", ["relu", "sigmoid", "linear", None, "softsign_callable", "torch_relu"])
+def test_bahdanau_attention_layer_with_another_activation(activation):
+    """BahdanauAttention(activation=...) (attention/attention.py:31,47): the named ones inside
+    the kernel, any other callable applied to the caller's tensor."""
+    import torch
+    from image_caption_amd.attention.attention import BahdanauAttention
+    rng = np.random.default_rng(17)
+    N, L, F, U, Hh = 6, 9, 24, 16, 12
+    p = {"att_W1_kernel": (rng.standard_normal((F, U)) * 0.3).astype(np.float32),
+         "att_W1_bias": (0.1 * rng.standard_normal(U)).astype(np.float32),
+         "att_W2_kernel": (rng.standard_normal((Hh, U)) * 0.3).astype(np.float32),
+         "att_W2_bias": (0.1 * rng.standard_normal(U)).astype(np.float32),
+         "att_V_kernel": rng.standard_normal((U, 1)).astype(np.float32),
+         "att_V_bias": np.asarray([0.2], np.float32)}
+    f = rng.standard_normal((N, L, F)).astype(np.float32)
+    h = rng.standard_normal((N, Hh)).astype(np.float32)
+    np_act = {"relu": lambda x: np.maximum(x, 0), "torch_relu": lambda x: np.maximum(x, 0),
+              "sigmoid": co.sigmoid, "linear": lambda x: x, None: lambda x: x,
+              "softsign_callable": lambda x: x / (1 + np.abs(x))}[activation]
+    arg = {"softsign_callable": torch.nn.functional.softsign, "torch_relu": torch.relu}.get(activation, activation)
+    layer = BahdanauAttention(U, activation=arg, device=dev())
+    layer.W1.set_weights(p["att_W1_kernel"], p["att_W1_bias"], dev())
+    layer.W2.set_weights(p["att_W2_kernel"], p["att_W2_bias"], dev())
+    layer.V.set_weights(p["att_V_kernel"], p["att_V_bias"], dev())
+    ctx, w = layer(to_dev(f), to_dev(h))
+    ctx_ref, w_ref = co.bahdanau_attention(f, h, p, activation=np_act)
+    assert tuple(w.shape) == (N, L, 1)
+    assert_close(np_of(w), w_ref, what="weights")
+    assert_close(np_of(ctx), ctx_ref, what="context")

@@ -232,6 +232,81 @@ def test_multi_head_attention_layer_with_and_without_mask(ops):
     assert_close(got, ref, what="mha bias-as-mask")
 
 
+def _general_params(rng, d_q, d_k, d_v, heads, kd, vd, out):
+    p = {}
+    for n, (i, o) in (("q", (d_q, heads * kd)), ("k", (d_k, heads * kd)), ("v", (d_v, heads * vd)),
+                      ("o", (heads * vd, out))):
+        p["g_" + n + "_kernel"] = (rng.standard_normal((i, o)) / np.sqrt(i)).astype(np.float32)
+        p["g_" + n + "_bias"] = (0.1 * rng.standard_normal(o)).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize("case", ["scores", "key_tensor", "value_dim", "output_shape", "no_bias",
+                                  "two_axes", "one_of_two_axes", "head_mask", "docstring_1d"])
+def test_multi_head_attention_general_forms(case):
+    """Every option of the reference's constructor / call signature the decoder stack does not
+    use (attention/attention.py:259-270,526-562), against the oracle's general restatement:
+    output and, where asked for, the attention probabilities."""
+    from image_caption_amd.attention.attention import MultiHeadAttention
+    rng = np.random.default_rng(11)
+    heads, kd = 3, 8
+    B, T, S, d = 3, 5, 7, 16
+    kw, okw = {}, {}
+    q_in = rng.standard_normal((B, T, d)).astype(np.float32)
+    v_in = rng.standard_normal((B, S, d)).astype(np.float32)
+    k_in, mask, vd, out_dim, d_k = None, None, kd, d, d
+    if case == "key_tensor":
+        d_k = 20
+        k_in = rng.standard_normal((B, S, d_k)).astype(np.float32)
+        mask = (rng.random((B, T, S)) > 0.3).astype(np.float32)
+        mask[..., 0] = 1
+    elif case == "value_dim":
+        vd = 12
+        kw["value_dim"] = okw["value_dim"] = vd
+    elif case == "output_shape":
+        out_dim = 10
+        kw["output_shape"] = okw["output_shape"] = (2, 5)
+    elif case == "no_bias":
+        kw["use_bias"] = okw["use_bias"] = False
+    elif case == "two_axes":
+        q_in = rng.standard_normal((2, 5, 3, 4, d)).astype(np.float32)
+        v_in = q_in
+        kw["attention_axes"] = okw["attention_axes"] = (2, 3)
+    elif case == "one_of_two_axes":
+        q_in = rng.standard_normal((2, 3, 4, d)).astype(np.float32)
+        v_in = rng.standard_normal((2, 3, 6, d)).astype(np.float32)
+        kw["attention_axes"] = okw["attention_axes"] = 2
+        mask = (rng.random((2, 3, 4, 6)) > 0.3).astype(np.float32)
+        mask[..., 0] = 1
+    elif case == "head_mask":
+        mask = (rng.random((B, heads, T, S)) > 0.3).astype(np.float32)
+        mask[..., 0] = 1
+    elif case == "docstring_1d":
+        heads, kd, vd = 2, 2, 2
+        q_in = rng.standard_normal((B, 8, 16)).astype(np.float32)
+        v_in = rng.standard_normal((B, 4, 16)).astype(np.float32)
+    p = _general_params(rng, d, d_k, d, heads, kd, vd, out_dim)
+    layer = MultiHeadAttention(heads, kd, device=dev(), **kw)
+    layer.set_weights(*[(p["g_%s_kernel" % n], p["g_%s_bias" % n]) for n in "qkvo"], device=dev())
+    got, probs = layer(to_dev(q_in), to_dev(v_in), key=None if k_in is None else to_dev(k_in),
+                       attention_mask=None if mask is None else to_dev(mask),
+                       return_attention_scores=True)
+    ref, ref_probs = co.multi_head_attention_general(q_in, v_in, p, "g_", heads, kd, key=k_in,
+                                                     attention_mask=mask, **okw)
+    assert tuple(got.shape) == ref.shape and tuple(probs.shape) == ref_probs.shape
+    assert_close(np_of(probs), ref_probs, what=case + " probabilities")
+    assert_close(np_of(got), ref, what=case + " output")
+    if case == "docstring_1d":        # the shapes of the reference's own example (`:204-210`)
+        assert tuple(got.shape) == (B, 8, 16) and tuple(probs.shape) == (B, 2, 8, 4)
+    if case == "two_axes":            # `:211-215`
+        assert tuple(got.shape) == (2, 5, 3, 4, 16)
+    if case in ("scores", "head_mask"):
+        # without the scores the same call takes the step kernel (or, with a head axis in the
+        # mask, the general one): same output
+        again = layer(to_dev(q_in), to_dev(v_in), attention_mask=None if mask is None else to_dev(mask))
+        assert_close(np_of(again), ref, what=case + " output without scores")
+
+
 def test_transform_decoder_module_steps_and_engine_agree():
     """The module API (full-prefix recompute per call, as the reference) against the oracle
     step, and the module-level decode loop against the fused engine."""

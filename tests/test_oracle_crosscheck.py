@@ -256,6 +256,77 @@ def test_multi_head_attention_matches_torch_sdpa(causal):
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
 
 
+def _mha_general_params(rng, d_q, d_k, d_v, heads, kd, vd, out):
+    p = {}
+    for n, (i, o) in (("q", (d_q, heads * kd)), ("k", (d_k, heads * kd)), ("v", (d_v, heads * vd)),
+                      ("o", (heads * vd, out))):
+        p["g_" + n + "_kernel"] = (rng.standard_normal((i, o)) / np.sqrt(i)).astype(np.float32)
+        p["g_" + n + "_bias"] = (0.1 * rng.standard_normal(o)).astype(np.float32)
+    return p
+
+
+def test_general_multi_head_attention_reduces_to_the_plain_form_and_to_torch():
+    """The oracle's general restatement (einsum equations rebuilt as the reference builds them)
+    equals the key = value restatement on a 3-D call, and torch's scaled dot-product attention
+    with a key tensor of its own and value_dim != key_dim."""
+    rng = np.random.default_rng(5)
+    B, T, S, d, heads, kd, vd = 2, 4, 6, 16, 3, 8, 12
+    q_in = rng.standard_normal((B, T, d)).astype(np.float32)
+    v_in = rng.standard_normal((B, S, d)).astype(np.float32)
+    k_in = rng.standard_normal((B, S, 20)).astype(np.float32)
+    p = _mha_general_params(rng, d, d, d, heads, kd, kd, d)
+    a, _ = co.multi_head_attention_general(q_in, v_in, p, "g_", heads, kd)
+    b = co.multi_head_attention(q_in, v_in, p, "g_", heads, kd)
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+    p = _mha_general_params(rng, d, 20, d, heads, kd, vd, 10)
+    got, scores = co.multi_head_attention_general(q_in, v_in, p, "g_", heads, kd, key=k_in, value_dim=vd,
+                                                  output_shape=10)
+    assert got.shape == (B, T, 10) and scores.shape == (B, heads, T, S)
+    np.testing.assert_allclose(scores.sum(-1), 1.0, rtol=1e-5)
+    t = lambda x: torch.from_numpy(x)
+    proj = lambda x, n, dd: (t(x) @ t(p["g_" + n + "_kernel"]) + t(p["g_" + n + "_bias"])).reshape(
+        x.shape[0], x.shape[1], heads, dd).permute(0, 2, 1, 3)
+    o = torch.nn.functional.scaled_dot_product_attention(proj(q_in, "q", kd), proj(k_in, "k", kd),
+                                                         proj(v_in, "v", vd))
+    ref = (o.permute(0, 2, 1, 3).reshape(B, T, heads * vd) @ t(p["g_o_kernel"]) + t(p["g_o_bias"])).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_general_multi_head_attention_shapes_of_the_reference_docstring():
+    """The two worked examples in the reference's class docstring (attention/attention.py:
+    202-215): target [B,8,16], source [B,4,16], 2 heads of 2 -> output (B,8,16), weights
+    (B,2,8,4); 2-D attention over axes (2,3) of a [B,5,3,4,16] input -> (B,5,3,4,16).  With two
+    attention axes the soft-max covers the last key axis only (Softmax(axis=-1), `:457-458`), so
+    the weights of a query position sum to the size of the other key axis."""
+    rng = np.random.default_rng(6)
+    B = 2
+    p = _mha_general_params(rng, 16, 16, 16, 2, 2, 2, 16)
+    target = rng.standard_normal((B, 8, 16)).astype(np.float32)
+    source = rng.standard_normal((B, 4, 16)).astype(np.float32)
+    out, w = co.multi_head_attention_general(target, source, p, "g_", 2, 2)
+    assert out.shape == (B, 8, 16) and w.shape == (B, 2, 8, 4)
+    x = rng.standard_normal((B, 5, 3, 4, 16)).astype(np.float32)
+    out, w = co.multi_head_attention_general(x, x, p, "g_", 2, 2, attention_axes=(2, 3))
+    assert out.shape == (B, 5, 3, 4, 16) and w.shape == (B, 5, 2, 3, 4, 3, 4)
+    np.testing.assert_allclose(w.sum(axis=(-1, -2)), 3.0, rtol=1e-5)
+
+
+def test_attention_with_another_activation_matches_torch():
+    rng = np.random.default_rng(8)
+    N, L, F, U = 3, 5, 6, 4
+    p = {"att_W1_kernel": rng.standard_normal((F, U)).astype(np.float32), "att_W1_bias": np.zeros(U, np.float32),
+         "att_W2_kernel": rng.standard_normal((7, U)).astype(np.float32), "att_W2_bias": np.zeros(U, np.float32),
+         "att_V_kernel": rng.standard_normal((U, 1)).astype(np.float32), "att_V_bias": np.zeros(1, np.float32)}
+    f = rng.standard_normal((N, L, F)).astype(np.float32)
+    h = rng.standard_normal((N, 7)).astype(np.float32)
+    ctx, w = co.bahdanau_attention(f, h, p, activation=lambda x: np.maximum(x, 0))
+    tf_, th = torch.from_numpy(f), torch.from_numpy(h)
+    hid = torch.relu(tf_ @ torch.from_numpy(p["att_W1_kernel"]) + (th @ torch.from_numpy(p["att_W2_kernel"]))[:, None])
+    tw = torch.softmax(hid @ torch.from_numpy(p["att_V_kernel"]), dim=1)
+    np.testing.assert_allclose(w, tw.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ctx, (tw * tf_).sum(1).numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_bias_passed_as_mask_gives_a_uniform_causal_mean():
     """The reference hands the additive causal bias to `attention_mask` (transform_decoder.py:
     139 -> attention.py:471-473): visible positions get -1e9 added in fp32, which absorbs the
