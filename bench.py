@@ -53,11 +53,18 @@ CONFIGS = {
     "transformer_b1024_fp32": dict(B=1024, W=3, L=64, F=2048, D=512, hidden=512, heads=512, key_dim=8,
                                    filter=2048, layers=6, V=10000, T=20, precision="fp32",
                                    loop="transformer"),
+    # the same stack in the conventional layout the engine's flags expose: 8 heads of 64, a
+    # causal mask, self-attention keys / values from the normalised input
+    "transformer_b1024_fp32_conventional": dict(B=1024, W=3, L=64, F=2048, D=512, hidden=512, heads=8,
+                                                key_dim=64, filter=2048, layers=6, V=10000, T=20,
+                                                precision="fp32", loop="transformer",
+                                                mask_mode="causal", kv_from_normed=True),
     "beam10_v50k_fp32": dict(B=256, W=10, L=196, F=512, D=256, E=256, H=512, U=512, V=50000, T=20,
                              precision="fp32"),
 }
 # passes per bench step (see the module docstring): sized so that 20 steps time about a second
-DEFAULT_INNER = {"transformer_b1024_fp32": 1, "beam10_v50k_fp32": 2}
+DEFAULT_INNER = {"transformer_b1024_fp32": 1, "transformer_b1024_fp32_conventional": 1,
+                 "beam10_v50k_fp32": 2}
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32-input MFMA peak of MI355X
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -205,6 +212,8 @@ def transformer_main(args, cfg, device, world, rank):
                        "decode_steps": cfg["T"], "layers": cfg["layers"], "hidden": H,
                        "heads": cfg["heads"], "key_dim": cfg["key_dim"], "filter": cfg["filter"],
                        "vocab": cfg["V"], "tile_mode": args.tile_mode,
+                       "mask_mode": cfg.get("mask_mode", "as_written"),
+                       "kv_from_normed": bool(cfg.get("kv_from_normed", False)),
                        "sharding": "images split over ranks, all-gather of sequences"},
             "roofline": {"bound": "mfma", "kernel": "attention projections dense_f32 (q, k|v, output; "
                          "5 launches per layer and pass)", "achieved": round(achieved, 2),
@@ -237,7 +246,9 @@ def cpu_baseline_transformer(cfg, budget_s=12.0):
     reps, t0 = 0, time.perf_counter()
     while True:
         co.predict_transformer_caption_sequence(p, img, cfg["W"], cfg["T"], 3, 4, cfg["layers"],
-                                                cfg["heads"], cfg["key_dim"])
+                                                cfg["heads"], cfg["key_dim"],
+                                                mask_mode=cfg.get("mask_mode", "as_written"),
+                                                kv_from_normed=cfg.get("kv_from_normed", False))
         reps += 1
         el = time.perf_counter() - t0
         if el >= budget_s or reps >= 20:

@@ -240,6 +240,76 @@ __global__ __launch_bounds__(NT) void mha_cross_step_kernel(CrossArgs p) {
   }
 }
 
+// The same for few, wide heads (heads * key_dim / CH <= NT / 2 chunks, a multiple of 64, e.g.
+// 8 heads of 64): one thread per chunk would leave most of the workgroup idle and one wave
+// walking all L positions, so NT / chunks groups of waves take every (NT / chunks)-th position
+// each and their soft-max states are joined through LDS (max of the maxima, sums and weighted
+// values rescaled to it).
+template <int CH, int RB>
+__global__ __launch_bounds__(NT) void mha_cross_step_split_kernel(CrossArgs p) {
+  __shared__ float s_m[NT * RB], s_l[NT * RB], s_acc[NT * RB * CH];
+  const int chunks = p.HD / CH;
+  const int nsplit = NT / chunks;
+  const int g = blockIdx.x;
+  const int c = threadIdx.x % chunks, split = threadIdx.x / chunks;
+  const float* kbase = p.kv + (size_t)g * p.L * 2 * p.HD + c * CH;
+  for (int k0 = 0; k0 < p.R; k0 += RB) {
+    float q[RB][CH];
+    Online<CH> st[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int k = min(k0 + r, p.R - 1);
+      const int n = g * p.stride_g + k * p.stride_k;
+      const Chunk<CH> qc = load_chunk<CH>(p.q + (size_t)n * p.HD + c * CH);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) q[r][e] = qc.e[e] * p.scale;
+      st[r].init();
+    }
+    const float* mrow = p.mask ? p.mask + (size_t)g * p.mask_stride_g : nullptr;
+    for (int j = split; j < p.L; j += nsplit) {
+      const Chunk<CH> kc = load_chunk<CH>(kbase + (size_t)j * 2 * p.HD);
+      const Chunk<CH> vc = load_chunk<CH>(kbase + (size_t)j * 2 * p.HD + p.HD);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        float sc = head_dot<CH>(q[r], kc, p.lph);
+        if (mrow) sc = sc + (1.0f - mrow[(size_t)min(k0 + r, p.R - 1) * p.L + j]) * -1e9f;
+        st[r].add(sc, vc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int o = r * NT + threadIdx.x;
+      s_m[o] = st[r].m;
+      s_l[o] = st[r].l;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) s_acc[(size_t)e * NT * RB + o] = st[r].acc[e];
+    }
+    __syncthreads();
+    if (split == 0) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int k = k0 + r;
+        if (k >= p.R) continue;
+        float m = -INFINITY;
+        for (int sp = 0; sp < nsplit; ++sp) m = fmaxf(m, s_m[r * NT + sp * chunks + c]);
+        float l = 0.f, acc[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const int o = r * NT + sp * chunks + c;
+          const float w = (s_m[o] > -INFINITY) ? fast_exp(s_m[o] - m) : 0.f;  // (a group without positions)
+          l += s_l[o] * w;
+#pragma unroll
+          for (int e = 0; e < CH; ++e) acc[e] += s_acc[(size_t)e * NT * RB + o] * w;
+        }
+        const int n = g * p.stride_g + k * p.stride_k;
+        store_chunk<CH>(p.out + (size_t)n * p.HD + c * CH, acc, 1.0f / l);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // x[i] += o[i % period]: the residual add of the pre-norm wrapper (period = n) and the
 // position-encoding add broadcast over the batch (period = length * hidden).
 __global__ __launch_bounds__(NT) void add_kernel(float* __restrict__ x, const float* __restrict__ o,
@@ -425,6 +495,15 @@ int mha_cross_step_f32(const float* q, const float* kv, float* out, int G, int r
   ICAP_REQUIRE((long long)G * cblocks < (1LL << 31), "mha_cross_step_f32: too many workgroups");
   const dim3 grid((unsigned)(G * cblocks)), block(NT);
   const int rb = rows_per_group >= 3 ? 3 : rows_per_group;   // rows per register pass
+  const int chunks = a.HD / ch;
+  if (ch == 8 && chunks <= NT / 2 && chunks % 64 == 0 && NT % chunks == 0 && L >= 2 * (NT / chunks)) {
+    // few wide heads: the positions are split over the workgroup's waves
+    if (rb == 1) hipLaunchKernelGGL((mha_cross_step_split_kernel<8, 1>), dim3(G), block, 0, s, a);
+    else if (rb == 2) hipLaunchKernelGGL((mha_cross_step_split_kernel<8, 2>), dim3(G), block, 0, s, a);
+    else hipLaunchKernelGGL((mha_cross_step_split_kernel<8, 3>), dim3(G), block, 0, s, a);
+    ICAP_LAUNCH_CHECK("mha_cross_step_split_kernel");
+    return ICAP_OK;
+  }
   if (ch == 8) {
     if (rb == 1) hipLaunchKernelGGL((mha_cross_step_kernel<8, 1>), grid, block, 0, s, a);
     else if (rb == 2) hipLaunchKernelGGL((mha_cross_step_kernel<8, 2>), grid, block, 0, s, a);

@@ -79,7 +79,10 @@ def test_mha_self_step(ops, N, heads, kd, pos, mask_mode):
 
 @pytest.mark.parametrize("G,R,L,heads,kd,mode", [
     (3, 1, 5, 4, 4, 0), (3, 3, 5, 4, 8, 0), (3, 3, 5, 4, 8, 1), (2, 5, 7, 2, 64, 0),
-    (4, 3, 64, 512, 8, 0), (4, 4, 9, 3, 16, 1)])
+    (4, 3, 64, 512, 8, 0), (4, 4, 9, 3, 16, 1),
+    # few wide heads: the positions of a group are split over the waves of its workgroup
+    (5, 3, 64, 8, 64, 0), (3, 3, 9, 8, 64, 1), (3, 4, 33, 16, 64, 0), (2, 2, 8, 8, 64, 0),
+    (2, 1, 7, 8, 64, 1)])
 def test_mha_cross_step(ops, G, R, L, heads, kd, mode):
     rng = np.random.default_rng(G * R + L + kd)
     HD, N = heads * kd, G * R
@@ -200,10 +203,11 @@ def _tmodules(p, dims):
     return dec
 
 
-def test_multi_head_attention_layer_with_and_without_mask(ops):
+@pytest.mark.parametrize("heads,kd", [(5, 8), (8, 64)])
+def test_multi_head_attention_layer_with_and_without_mask(ops, heads, kd):
     from image_caption_amd.attention.attention import MultiHeadAttention, get_decoder_self_attention_bias
     rng = np.random.default_rng(3)
-    B, T, S, dim, heads, kd = 3, 4, 6, 16, 5, 8
+    B, T, S, dim = 3, 4, 6, 16
     q_in = rng.standard_normal((B, T, dim)).astype(np.float32)
     v_in = rng.standard_normal((B, S, 12)).astype(np.float32)
     p = {}
