@@ -23,6 +23,8 @@
 
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "beam_records_body.h"
 #include "beam_shared.h"
 #include "icap_common.h"
@@ -500,6 +502,242 @@ __global__ __launch_bounds__(256) void beam_records_kernel(RecArgs p) {
   beam_records_body<WL, ITEMS, 256>(p, blockIdx.x, lds);
 }
 
+// ---- the same step with one wave per beam row ----
+// Within a row the score is a non-decreasing function of the logit (same log-prob, same
+// log-sum-exp, same positive penalty), so a row's successors are among its W largest recorded
+// logits: wave w folds the records of row w into (max, log-sum-exp) and selects those W on
+// 64-bit keys, (logit in an order-preserving integer form) << 32 | ~column, whose unsigned
+// order is "higher logit first, then lower column".  A lane merges the sorted lists of its
+// records into one sorted list of WL keys, and the DPP ladder of wave_max merges the lanes'
+// lists (max of one list against the other reversed leaves the WL largest of both, a fixed
+// sorting network orders them): straight-line code, no barrier, no rescans.  Only these W and
+// the row's special candidates (the eos column with its own penalty; the synthetic
+// candidates of a finished row) are scored with the exact division, 2W + 2 per row at most;
+// after ONE barrier wave 0 ranks the image's W * (2W + 2) <= 60 candidates, one per lane, with
+// the same network on (score, ~flat index) keys and writes the step's outputs.
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned ord_f32(float x) {  // unsigned order == float order (-0 as +0)
+  unsigned bts = __float_as_uint(x);
+  bts = (bts == 0x80000000u) ? 0u : bts;
+  return (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ u64 make_key(float x, int idx) {
+  return ((u64)ord_f32(x) << 32) | (unsigned)~idx;
+}
+__device__ __forceinline__ void key_cswap(u64& hi, u64& lo) {  // descending compare-exchange
+  const bool g = hi >= lo;
+  const u64 h = g ? hi : lo, l = g ? lo : hi;
+  hi = h;
+  lo = l;
+}
+template <int N>
+__device__ __forceinline__ void key_sort(u64 (&c)[N]) {
+  static_assert(N == 1 || N == 3 || N == 5, "networks for 1, 3 and 5 keys");
+  if constexpr (N == 3) {
+    key_cswap(c[0], c[2]); key_cswap(c[0], c[1]); key_cswap(c[1], c[2]);
+  } else if constexpr (N == 5) {
+    key_cswap(c[0], c[1]); key_cswap(c[3], c[4]); key_cswap(c[2], c[4]);
+    key_cswap(c[2], c[3]); key_cswap(c[1], c[4]); key_cswap(c[0], c[3]);
+    key_cswap(c[0], c[2]); key_cswap(c[1], c[3]); key_cswap(c[1], c[2]);
+  }
+}
+// a, b sorted descending -> a = the N largest of both, sorted descending
+template <int N>
+__device__ __forceinline__ void key_merge(u64 (&a)[N], const u64 (&b)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = a[i] >= b[N - 1 - i] ? a[i] : b[N - 1 - i];
+  key_sort<N>(a);
+}
+template <int CTRL, int MASK, int N>
+__device__ __forceinline__ void key_ladder_step(u64 (&k)[N]) {
+  u64 o[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const unsigned lo = (unsigned)dpp_i<CTRL, MASK>(0, (int)(unsigned)k[i]);
+    const unsigned hi = (unsigned)dpp_i<CTRL, MASK>(0, (int)(unsigned)(k[i] >> 32));
+    o[i] = ((u64)hi << 32) | lo;
+  }
+  key_merge<N>(k, o);
+}
+// every lane hands in a descending list; every lane gets the N largest keys of the wave
+template <int N>
+__device__ __forceinline__ void wave_top_keys(u64 (&k)[N]) {
+  key_ladder_step<ICAP_DPP_ROW_SHR(1), 0xf, N>(k);
+  key_ladder_step<ICAP_DPP_ROW_SHR(2), 0xf, N>(k);
+  key_ladder_step<ICAP_DPP_ROW_SHR(4), 0xf, N>(k);
+  key_ladder_step<ICAP_DPP_ROW_SHR(8), 0xf, N>(k);
+  key_ladder_step<ICAP_DPP_BCAST15, 0xa, N>(k);
+  key_ladder_step<ICAP_DPP_BCAST31, 0xc, N>(k);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k[i], 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k[i] >> 32), 63);
+    k[i] = ((u64)hi << 32) | lo;
+  }
+}
+
+template <int WL, int ITEMS>
+__global__ __launch_bounds__(64 * WL) void beam_records_rows_kernel(RecArgs p) {
+  constexpr int RL = 2 + 2 * WL;
+  constexpr int NC = 2 * WL + 2;  // candidates a row hands over: W picks, then W + 2 special ones
+  __shared__ float s_sc[WL][NC], s_tot[WL][NC];
+  __shared__ int s_idx[WL][NC];
+  __shared__ int s_fin[WL], s_len[WL];
+  __shared__ float s_wt[WL];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int W = p.W, V = p.V, HT = p.HT;
+  const bool first = p.time <= 0;
+  const int n_rows = first ? 1 : W;  // time 0 scores beam 0 only
+  const size_t row0 = (size_t)b * W;
+
+  if (w < n_rows) {  // (uniform over the wave)
+    // ---- every load of the wave is issued here: lane l owns records l, l + 64, ... ----
+    const float* rbase = p.rec + ((size_t)b * p.rpi + w) * HT * RL;
+    float4 rr[ITEMS][RL / 4];
+    bool okr[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = lane + it * 64;
+      okr[it] = idx < HT;
+      const float4* src = reinterpret_cast<const float4*>(rbase + (size_t)(okr[it] ? idx : 0) * RL);
+#pragma unroll
+      for (int q = 0; q < RL / 4; ++q) rr[it][q] = src[q];
+    }
+    const float lp = p.log_probs[row0 + w];
+    const int len = p.lengths[row0 + w];
+    const bool fin = p.finished[row0 + w] != 0;
+    const float eos_x = p.eos_x[(size_t)b * p.rpi + w];
+
+    // ---- row statistics ----
+    float m = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) m = okr[it] ? fmaxf(m, rr[it][0].x) : m;
+    const float M = wave_max(m);
+    float sm = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const float t = rr[it][0].y * fast_exp(rr[it][0].x - M);
+      sm += (okr[it] && rr[it][0].x > -INFINITY) ? t : 0.f;
+    }
+    const float lse = logf(wave_sum(sm));
+
+    // ---- the row's W largest logits (the eos column is scored apart, a finished row has none) ----
+    u64 top[WL];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const float* fl = reinterpret_cast<const float*>(&rr[it][0]);
+      u64 lst[WL];
+#pragma unroll
+      for (int k = 0; k < WL; ++k) {
+        const float x = fl[2 + k];
+        const int col = __float_as_int(fl[2 + WL + k]);
+        const bool ok = okr[it] && !fin && col >= 0 && col < V && col != p.eos && x == x;
+        lst[k] = ok ? make_key(x, col) : 0ull;
+      }
+      // a record is sorted; the one entry dropped from its middle (the eos column) sinks to the end
+#pragma unroll
+      for (int k = 0; k + 1 < WL; ++k) key_cswap(lst[k], lst[k + 1]);
+      if (it == 0) {
+#pragma unroll
+        for (int k = 0; k < WL; ++k) top[k] = lst[k];
+      } else {
+        key_merge<WL>(top, lst);
+      }
+    }
+    wave_top_keys<WL>(top);
+    u64 mykey = 0ull;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) mykey = (lane == k) ? top[k] : mykey;
+
+    // ---- exact scores: lanes 0..W-1 the picks, lanes W..2W+1 the special candidates ----
+    float sc = -INFINITY, tot = 0.f;
+    int fi = EMPTY_IDX;
+    const int flat0 = first ? 0 : w * V;
+    if (lane < W) {
+      if (mykey != 0ull) {
+        const float x = unord_f32((unsigned)(mykey >> 32));
+        const int col = (int)~(unsigned)mykey;
+        tot = lp + ((x - M) - lse);
+        const float s = tot / penalty_of(p.pen, len + 1);
+        if (s == s) { sc = s; fi = flat0 + col; }
+      }
+    } else if (lane < 2 * W + 2) {
+      const int j = lane - W;
+      const float pen = penalty_of(p.pen, len);
+      if (fin) {
+        // all mass on eos: only the first W+1 columns and the eos column can be selected
+        const int ncol = min(V, W + 1);
+        int col = -1;
+        if (j < ncol) col = j;
+        else if (j == ncol && p.eos >= ncol && p.eos < V) col = p.eos;
+        if (col >= 0) {
+          tot = lp + ((col == p.eos) ? 0.f : kF32Min);
+          sc = tot / pen;
+          fi = flat0 + col;
+        }
+      } else if (j == 0 && p.eos >= 0 && p.eos < V) {
+        tot = lp + ((eos_x - M) - lse);
+        const float s = tot / pen;
+        if (s == s) { sc = s; fi = flat0 + p.eos; }
+      }
+    }
+    if (lane < NC) { s_sc[w][lane] = sc; s_tot[w][lane] = tot; s_idx[w][lane] = fi; }
+    if (lane == 0) { s_fin[w] = fin ? 1 : 0; s_len[w] = len; }
+  }
+  __syncthreads();
+  if (w != 0) return;
+
+  // ---- wave 0: the image's candidates, one per lane; the W best by (score, flat index) ----
+  float ct = 0.f;
+  u64 ckey = 0ull;
+  {
+    const int r = lane / NC, q = lane - r * NC;
+    if (r < n_rows && q < 2 * W + 2) {
+      const int ci = s_idx[r][q];
+      ct = s_tot[r][q];
+      ckey = (ci == EMPTY_IDX) ? 0ull : make_key(s_sc[r][q], ci);
+    }
+  }
+  u64 best[WL];
+  best[0] = ckey;
+#pragma unroll
+  for (int k = 1; k < WL; ++k) best[k] = 0ull;
+  wave_top_keys<WL>(best);
+  // the winners' running log-probs come back through LDS (flat indices are unique)
+  if (lane < WL) s_wt[lane] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int k = 0; k < WL; ++k)
+    if (ckey != 0ull && ckey == best[k]) s_wt[k] = ct;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  u64 mine = 0ull;
+#pragma unroll
+  for (int k = 0; k < WL; ++k) mine = (lane == k) ? best[k] : mine;
+  if (lane < W) {
+    const bool none = mine == 0ull;
+    const float my_s = none ? -INFINITY : unord_f32((unsigned)(mine >> 32));
+    const int flat = none ? 0 : (int)~(unsigned)mine;
+    const int word = flat % V;
+    const int parent = flat / V;  // (< n_rows: flat indices come from scored rows only)
+    const int pfin = s_fin[parent], plen = s_len[parent];
+    const int nfin = (pfin || word == p.eos) ? 1 : 0;
+    const int nlen = plen + ((word != p.eos && !nfin) ? 1 : 0);
+    // (the next-state buffers may be the state inputs: every read of the state happened
+    // before the barrier)
+    const size_t o = row0 + lane;
+    p.scores[o] = my_s;
+    p.ids[o] = word;
+    p.parents[o] = parent;
+    p.next_lp[o] = s_wt[lane];
+    p.next_fin[o] = (uint8_t)nfin;
+    p.next_len[o] = nlen;
+  }
+}
+
 // ---- the same step for wide beams (W up to 16) and any number of records per image ----
 // The records hold each half tile's best WL (< W) logits, so a half tile can hide candidates:
 // the kernel proves for every image that none of them matters, and raises *overflow
@@ -948,6 +1186,27 @@ int beam_step_from_records_f32(const float* records, const float* eos_logit, int
   a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
   a.B = B; a.W = W; a.V = V;
   a.pen = make_penalty(length_penalty_weight);
+  // One wave per beam row while a lane holds at most 8 records of its row; the one-workgroup
+  // form otherwise (and on request: ICAP_BEAM_RECORDS_FORM=wg, a tuning knob).
+  const int row_items = ceil_div(half_tiles, 64);
+  static const char* form_env = getenv("ICAP_BEAM_RECORDS_FORM");
+  if (row_items <= 8 && !(form_env && form_env[0] == 'w')) {
+    const dim3 grid(B);
+#define ICAP_ROWS_LAUNCH(WL_)                                                                        \
+  {                                                                                                  \
+    const dim3 block(64 * WL_);                                                                      \
+    if (row_items <= 2) hipLaunchKernelGGL((beam_records_rows_kernel<WL_, 2>), grid, block, 0, s, a);      \
+    else if (row_items <= 3) hipLaunchKernelGGL((beam_records_rows_kernel<WL_, 3>), grid, block, 0, s, a); \
+    else if (row_items <= 4) hipLaunchKernelGGL((beam_records_rows_kernel<WL_, 4>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((beam_records_rows_kernel<WL_, 8>), grid, block, 0, s, a);                     \
+  }
+    if (top_k == 1) ICAP_ROWS_LAUNCH(1)
+    else if (top_k == 3) ICAP_ROWS_LAUNCH(3)
+    else ICAP_ROWS_LAUNCH(5)
+#undef ICAP_ROWS_LAUNCH
+    ICAP_LAUNCH_CHECK("beam_records_rows_kernel");
+    return ICAP_OK;
+  }
   const int items = ceil_div((time <= 0 ? 1 : W) * half_tiles, 256);
   const dim3 grid(B), block(256);
 #define ICAP_REC_LAUNCH(WL_)                                                                    \
