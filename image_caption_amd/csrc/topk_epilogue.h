@@ -57,6 +57,10 @@ __device__ __forceinline__ void apply_logit_masks(float (&x)[NX], int cbase, int
 }
 
 // x[e] is the logit of column cbase + e; invalid columns must hold -inf.
+// The list stays sorted, so "v beats entry k-1" implies "v beats entry k" and the new entry k
+// is the median of (entry k-1, entry k, v): one v_med3_f32 per level for the values, two
+// selects per level for the columns.  The eos logit is picked out only in the wave whose
+// columns hold it (a wave-uniform branch), not by a compare per element.
 template <int TOPK, int NX>
 __device__ __forceinline__ TopkRow<TOPK> topk_scan(const float (&x)[NX], int cbase, int eos) {
   TopkRow<TOPK> r;
@@ -64,22 +68,33 @@ __device__ __forceinline__ TopkRow<TOPK> topk_scan(const float (&x)[NX], int cba
   for (int k = 0; k < TOPK; ++k) { r.tx[k] = -INFINITY; r.tc[k] = TOPK_EMPTY; }
   r.eos_v = 0.f;
   r.has_eos = false;
+  {
+    const int e_eos = eos - cbase;
+    const bool hit = (unsigned)e_eos < (unsigned)NX;
+    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+      float ev = x[0];
+#pragma unroll
+      for (int e = 1; e < NX; ++e) ev = (e_eos == e) ? x[e] : ev;
+      r.eos_v = ev;
+      r.has_eos = hit;
+    }
+  }
 #pragma unroll
   for (int e = 0; e < NX; ++e) {
     const float v = x[e];
     const int c = cbase + e;
-    if (c == eos) { r.eos_v = v; r.has_eos = true; }
     // insert (v, c) into the descending list; strict '>' keeps the lower column on ties
     bool gt[TOPK];
 #pragma unroll
     for (int k = 0; k < TOPK; ++k) gt[k] = v > r.tx[k];
 #pragma unroll
     for (int k = TOPK - 1; k >= 1; --k) {
-      r.tx[k] = gt[k - 1] ? r.tx[k - 1] : (gt[k] ? v : r.tx[k]);
-      r.tc[k] = gt[k - 1] ? r.tc[k - 1] : (gt[k] ? c : r.tc[k]);
+      const int below = gt[k] ? c : r.tc[k];
+      r.tc[k] = gt[k - 1] ? r.tc[k - 1] : below;
+      r.tx[k] = __builtin_amdgcn_fmed3f(r.tx[k - 1], r.tx[k], v);
     }
-    r.tx[0] = gt[0] ? v : r.tx[0];
     r.tc[0] = gt[0] ? c : r.tc[0];
+    r.tx[0] = __builtin_fmaxf(r.tx[0], v);
   }
   r.m = r.tx[0];
   const float ms = (r.m > -INFINITY) ? r.m : 0.f;
