@@ -74,6 +74,21 @@ __device__ __forceinline__ float att_act(float x) {
   else return fast_tanh(x);
 }
 
+// Batched, branch-free loads for the vector path: LB locations' rows in flight per wave.  Lanes
+// whose columns lie beyond n read the row's first vector instead (finite values that only meet
+// zero weights or never reach a store), so no load sits behind a branch and its wait.
+template <int LB, int CH, int WAVES>
+__device__ __forceinline__ void att_load_batch(float4 (&x)[LB][CH], const float* __restrict__ base,
+                                               int row_floats, const int (&off)[CH], int l0, int L) {
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = min(l0 + b * WAVES, L - 1);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      x[b][ch] = *reinterpret_cast<const float4*>(base + (size_t)l * row_floats + off[ch]);
+  }
+}
+
 // RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.  The
 // workgroup (NT threads) walks work items first, first + stride, ...
 template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH>
@@ -128,26 +143,22 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
 #pragma unroll
       for (int ch = 0; ch < UCH; ++ch) q4[r][ch] = att_ld4<VEC>(qrow, ch * 256 + lane * 4, p.U);
     }
-    for (int l = wave; l < p.L; l += WAVES) {
-      float4 x[UCH];
-#pragma unroll
-      for (int ch = 0; ch < UCH; ++ch)
-        x[ch] = att_ld4<VEC>(pf_g + (size_t)l * p.U, ch * 256 + lane * 4, p.U);
-      float part[RB];
+    auto score_location = [&](const float4 (&x)[UCH], int l) {
+      float a[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        part[r] = 0.f;
-        if (k0 + r >= ke) continue;  // uniform: the last block may hold fewer rows
-        float a = 0.f;
+        a[r] = 0.f;
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch) {
-          a += v4[ch].x * att_act<ACT>(x[ch].x + q4[r][ch].x);
-          a += v4[ch].y * att_act<ACT>(x[ch].y + q4[r][ch].y);
-          a += v4[ch].z * att_act<ACT>(x[ch].z + q4[r][ch].z);
-          a += v4[ch].w * att_act<ACT>(x[ch].w + q4[r][ch].w);
+          a[r] += v4[ch].x * att_act<ACT>(x[ch].x + q4[r][ch].x);
+          a[r] += v4[ch].y * att_act<ACT>(x[ch].y + q4[r][ch].y);
+          a[r] += v4[ch].z * att_act<ACT>(x[ch].z + q4[r][ch].z);
+          a[r] += v4[ch].w * att_act<ACT>(x[ch].w + q4[r][ch].w);
         }
-        part[r] = wave_sum(a);
       }
+      float part[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) part[r] = (k0 + r < ke) ? wave_sum(a[r]) : 0.f;  // (uniform)
       if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -161,6 +172,35 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
             s_w[k * p.L + l] = sc;
           }
         }
+      }
+    };
+    if constexpr (VEC) {
+      // two register sets of LB locations each: the next set's loads are in flight while the
+      // current one is scored (same locations per wave and same order as the plain loop)
+      constexpr int LB = (RB * UCH <= 6) ? 4 : 2;
+      constexpr int STEP = WAVES * LB;
+      int off[UCH];
+#pragma unroll
+      for (int ch = 0; ch < UCH; ++ch) off[ch] = (ch * 256 + lane * 4 + 3 < p.U) ? ch * 256 + lane * 4 : 0;
+      float4 xa[LB][UCH], xb[LB][UCH];
+      att_load_batch<LB, UCH, WAVES>(xa, pf_g, p.U, off, wave, p.L);
+      for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
+        att_load_batch<LB, UCH, WAVES>(xb, pf_g, p.U, off, l0 + STEP, p.L);
+#pragma unroll
+        for (int b = 0; b < LB; ++b)
+          if (l0 + b * WAVES < p.L) score_location(xa[b], l0 + b * WAVES);
+        att_load_batch<LB, UCH, WAVES>(xa, pf_g, p.U, off, l0 + 2 * STEP, p.L);
+#pragma unroll
+        for (int b = 0; b < LB; ++b)
+          if (l0 + STEP + b * WAVES < p.L) score_location(xb[b], l0 + STEP + b * WAVES);
+      }
+    } else {
+      for (int l = wave; l < p.L; l += WAVES) {
+        float4 x[UCH];
+#pragma unroll
+        for (int ch = 0; ch < UCH; ++ch)
+          x[ch] = att_ld4<VEC>(pf_g + (size_t)l * p.U, ch * 256 + lane * 4, p.U);
+        score_location(x, l);
       }
     }
   }
@@ -195,8 +235,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
       float4 acc[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int l = wave; l < p.L; l += WAVES) {
-        const float4 f = att_ld4<VEC>(f_g + (size_t)l * p.D, d, p.D);
+      auto add_location = [&](const float4& f, int l) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const float w = s_w[min(k0 + r, ke - 1) * p.L + l];
@@ -205,6 +244,24 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
           acc[r].z += w * f.z;
           acc[r].w += w * f.w;
         }
+      };
+      if constexpr (VEC) {
+        constexpr int LB = 4, STEP = WAVES * LB;
+        const int off[1] = {(d + 3 < p.D) ? d : 0};
+        float4 fa[LB][1], fb[LB][1];
+        att_load_batch<LB, 1, WAVES>(fa, f_g, p.D, off, wave, p.L);
+        for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
+          att_load_batch<LB, 1, WAVES>(fb, f_g, p.D, off, l0 + STEP, p.L);
+#pragma unroll
+          for (int b = 0; b < LB; ++b)
+            if (l0 + b * WAVES < p.L) add_location(fa[b][0], l0 + b * WAVES);
+          att_load_batch<LB, 1, WAVES>(fa, f_g, p.D, off, l0 + 2 * STEP, p.L);
+#pragma unroll
+          for (int b = 0; b < LB; ++b)
+            if (l0 + STEP + b * WAVES < p.L) add_location(fb[b][0], l0 + STEP + b * WAVES);
+        }
+      } else {
+        for (int l = wave; l < p.L; l += WAVES) add_location(att_ld4<VEC>(f_g + (size_t)l * p.D, d, p.D), l);
       }
       if (d < dpad) {
 #pragma unroll
