@@ -126,6 +126,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
         *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_ch * 16) = rb[j];               \
   }
 
+  // LSTM / GRU epilogue operands of this thread's (row, unit) pairs - the token-only gate
+  // pre-activations (a gather by id) and the previous state - are fetched here, ahead of the
+  // K loop: inside the epilogue's row loop every iteration would wait out its own id ->
+  // row -> value chain behind the previous iteration's stores.
+  constexpr int NQ = LSTM ? BM / (NT / 32) : 1;
+  float ep_pre[NQ][4], st_pre[NQ];
+  if constexpr (LSTM) {
+    const int unit = (n0 >> 2) + (tid & 31);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1);  // (clamped rows are never stored)
+      const size_t o = (size_t)m * p.H + unit;
+      st_pre[q] = p.gru ? p.a1[o] : p.c_in[o];  // (a1 is the previous state h [N,H])
+      if (p.emb_proj) {  // (uniform)
+        int id = p.ids[m];
+        id = min(max(id, 0), p.V - 1);
+        const float* ep = p.emb_proj + (size_t)id * 4 * p.H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ep_pre[q][g] = ep[g * p.H];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ep_pre[q][g] = 0.f;
+      }
+    }
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -251,28 +277,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     float bz[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bz[g] = p.bias ? p.bias[g * H + unit] : 0.f;
-    for (int row = tid >> 5; row < BM; row += NT / 32) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = (tid >> 5) + q * (NT / 32);
       const int m = m0 + row;
-      if (m >= p.M) break;
       float z[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) z[g] = zs[row * ZLD + g * 32 + u] + bz[g];
-      if (p.emb_proj) {
-        int id = p.ids[m];
-        id = min(max(id, 0), p.V - 1);
-        const float* ep = p.emb_proj + (size_t)id * 4 * H + unit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += ep[g * H];
-      }
+      for (int g = 0; g < 4; ++g) z[g] = (zs[row * ZLD + g * 32 + u] + bz[g]) + ep_pre[q][g];
       const size_t o = (size_t)m * H + unit;
-      if (p.gru) {
-        const float zg = fast_sigmoid(z[0]), rg = fast_sigmoid(z[1]);
-        const float hh = fast_tanh(z[2] + rg * z[3]);
-        p.h_out[o] = zg * p.a1[o] + (1.f - zg) * hh;   // a1 is the previous state h [N,H]
-      } else {
-        const float cn = fast_sigmoid(z[1]) * p.c_in[o] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
-        p.c_out[o] = cn;
-        p.h_out[o] = fast_sigmoid(z[3]) * fast_tanh(cn);
+      if (m < p.M) {
+        if (p.gru) {
+          const float zg = fast_sigmoid(z[0]), rg = fast_sigmoid(z[1]);
+          const float hh = fast_tanh(z[2] + rg * z[3]);
+          p.h_out[o] = zg * st_pre[q] + (1.f - zg) * hh;
+        } else {
+          const float cn = fast_sigmoid(z[1]) * st_pre[q] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
+          p.c_out[o] = cn;
+          p.h_out[o] = fast_sigmoid(z[3]) * fast_tanh(cn);
+        }
       }
     }
   }

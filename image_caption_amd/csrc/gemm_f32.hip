@@ -844,6 +844,26 @@ __device__ __forceinline__ void cell_update(const LstmArgs& p, size_t o, float z
   }
 }
 
+// The same update with the previous state (c for the LSTM, h for the GRU) already in a register.
+template <int CELL>
+__device__ __forceinline__ void cell_update_pre(const LstmArgs& p, size_t o, float z0, float z1,
+                                                float z2, float z3, float prev) {
+  if (CELL == CELL_LSTM) {
+    const float ig = fast_sigmoid(z0);
+    const float fg = fast_sigmoid(z1);
+    const float gg = fast_tanh(z2);
+    const float og = fast_sigmoid(z3);
+    const float c_new = fg * prev + ig * gg;
+    p.c_out[o] = c_new;
+    p.h_out[o] = og * fast_tanh(c_new);
+  } else {
+    const float zg = fast_sigmoid(z0);
+    const float rg = fast_sigmoid(z1);
+    const float hh = fast_tanh(z2 + rg * z3);
+    p.h_out[o] = zg * prev + (1.f - zg) * hh;
+  }
+}
+
 template <bool VEC, int CELL>
 __global__ __launch_bounds__(256) void lstm_f32_kernel(LstmArgs p) {
   constexpr int NT = 256;
@@ -1085,6 +1105,19 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     ep[r] = ok ? v : 0.f;
   }
 
+  // the previous state of this thread's (row, unit) pairs for the cell update, fetched ahead
+  // of the K loop too: loaded inside the update loop, every iteration's load would have to
+  // stay behind the previous iteration's stores (the buffers may alias) and wait out its own
+  // memory latency
+  constexpr int NQ = BM * 32 / LW_NT;
+  float st_pre[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int gm = min(m0 + (tid >> 5) + (LW_NT / 32) * q, p.N - 1);
+    const size_t o = (size_t)gm * p.H + j0 + (tid & 31);
+    st_pre[q] = (CELL == CELL_LSTM) ? p.c[o] : p.h[o];
+  }
+
   // Staging offsets (elements).  The B tile does not divide evenly over 768 threads: the
   // surplus threads of the last pass repeat the tile's last vector (same address, same
   // LDS slot, same value), which keeps the loads free of control flow.
@@ -1176,8 +1209,8 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int row = (tid >> 5) + (LW_NT / 32) * q;
     const int gm = m0 + row;
     if (gm < p.N)
-      cell_update<CELL>(p, (size_t)gm * p.H + j0 + u, Zs[0][row][u], Zs[1][row][u], Zs[2][row][u],
-                        Zs[3][row][u]);
+      cell_update_pre<CELL>(p, (size_t)gm * p.H + j0 + u, Zs[0][row][u], Zs[1][row][u], Zs[2][row][u],
+                            Zs[3][row][u], st_pre[q]);
   }
 }
 
