@@ -10,12 +10,26 @@
 //
 // Tile: BM x 128 x 64 per stage, waves in a 2 x 2 grid, LDS double-buffered, the global
 // loads of stage k+1 in flight during the MFMAs of stage k, one barrier per stage.  LDS
-// rows are 144 bytes (128 of data + 16 pad) so that the 16-byte operand reads of 8
-// consecutive lanes fall in 8 distinct bank groups.
+// rows are 128 bytes with their eight 16-byte chunks XOR-swizzled by (row >> 1) & 7: the
+// lanes of a ds_read_b128 group (sixteen rows, one chunk index) then touch every bank once,
+// and without padding a 64-row stage pair is 48 KB (three workgroups per compute unit) and
+// a 128-row one 64 KB.
 #include <stdlib.h>
 
 #include "icap_common.h"
 #include "topk_epilogue.h"
+
+#ifdef ICAP_TIMELINE
+// Experiment builds only (-DICAP_TIMELINE): every workgroup of gemm_bf16_kernel leaves the
+// 100 MHz clock at four points of its life, read back through icap_debug_timeline.
+__device__ long long g_timeline[8192][4];
+#define ICAP_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) g_timeline[blockIdx.x][i] = wall_clock64();
+extern "C" int icap_debug_timeline(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(long long) * 4 * (n < 8192 ? n : 8192));
+}
+#else
+#define ICAP_STAMP(i)
+#endif
 
 namespace icap {
 namespace {
@@ -25,7 +39,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;
 constexpr int BN = 128;
-constexpr int ROW_B = BK * 2 + 16;  // bytes per LDS tile row
+constexpr int ROW_B = BK * 2;  // bytes per LDS tile row: 8 chunks of 16 bytes, chunk c of row r at c ^ ((r >> 1) & 7)
 constexpr int ZLD = BN + 4;         // floats per row of the gate exchange buffer
 
 struct Bf16Args {
@@ -62,7 +76,7 @@ struct Bf16Args {
 // the operand traffic, and at the vocab projection's shape the 2.6 MB activation panel then
 // stays in an XCD's L2 beside its band of weight panels.
 template <int BM, bool LSTM, int TOPK = 0, bool A16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
+__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Args p) {
   constexpr int NT = 256;
   constexpr int WTM = BM / 2;    // wave tile rows
   constexpr int TM = WTM / 32;   // accumulators along m
@@ -78,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   constexpr int SMEM = 2 * STAGE > Z_BYTES ? 2 * STAGE : Z_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
+  ICAP_STAMP(0)
   int tile_m, tile_n;
   tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -88,6 +103,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   // ---- global -> register staging ----
   const int a_c4 = tid & 15, a_r = tid >> 4;  // 16 rows per pass
   const int b_ch = tid & 7, b_r = tid >> 3;   // 32 rows per pass
+  // swizzled byte offsets inside an LDS row (a pass advances the row by 16 or 32: same swizzle)
+  const int b_sw = (b_ch ^ ((b_r >> 1) & 7)) << 4;
+  const int a_sw = (((a_c4 >> 1) ^ ((a_r >> 1) & 7)) << 4) | ((a_c4 & 1) << 3);
+  int rd_sw[BK / 16];  // chunk 2*ks + half of this lane's row (wave tiles start on multiples of 16 rows)
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) rd_sw[ks] = ((2 * ks + half) ^ ((l31 >> 1) & 7)) << 4;
   int a_row[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i)  // clamped, stores are masked
@@ -114,43 +135,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     char* bs_ = as_ + A_BYTES;                                                                     \
     _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                             \
       if (A16) {                                                                                   \
-        *reinterpret_cast<float4*>(as_ + (b_r + 32 * i) * ROW_B + b_ch * 16) = ra[i];              \
+        *reinterpret_cast<float4*>(as_ + (b_r + 32 * i) * ROW_B + b_sw) = ra[i];                   \
       } else {                                                                                     \
         bf16x4 v_;                                                                                 \
         v_[0] = (__bf16)ra[i].x; v_[1] = (__bf16)ra[i].y;                                          \
         v_[2] = (__bf16)ra[i].z; v_[3] = (__bf16)ra[i].w;                                          \
-        *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_c4 * 8) = v_;                  \
+        *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_sw) = v_;                      \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                               \
-        *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_ch * 16) = rb[j];               \
+        *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_sw) = rb[j];                    \
   }
 
   // LSTM / GRU epilogue operands of this thread's (row, unit) pairs - the token-only gate
   // pre-activations (a gather by id) and the previous state - are fetched here, ahead of the
   // K loop: inside the epilogue's row loop every iteration would wait out its own id ->
   // row -> value chain behind the previous iteration's stores.
+  // (64-row tiles; 128-row tiles hold too many pairs per thread to keep them across the loop
+  // and fetch them in one batch right behind it instead)
   constexpr int NQ = LSTM ? BM / (NT / 32) : 1;
+  constexpr bool HOIST = NQ <= 8;
   float ep_pre[NQ][4], st_pre[NQ];
-  if constexpr (LSTM) {
-    const int unit = (n0 >> 2) + (tid & 31);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int m = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1);  // (clamped rows are never stored)
-      const size_t o = (size_t)m * p.H + unit;
-      st_pre[q] = p.gru ? p.a1[o] : p.c_in[o];  // (a1 is the previous state h [N,H])
-      if (p.emb_proj) {  // (uniform)
-        int id = p.ids[m];
-        id = min(max(id, 0), p.V - 1);
-        const float* ep = p.emb_proj + (size_t)id * 4 * p.H + unit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ep_pre[q][g] = ep[g * p.H];
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ep_pre[q][g] = 0.f;
-      }
-    }
+#define ICAP_BF16_CELL_OPERANDS                                                                    \
+  {                                                                                                \
+    const int unit_ = (n0 >> 2) + (tid & 31);                                                      \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                               \
+      const int m_ = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1); /* clamped rows are never stored */ \
+      const size_t o_ = (size_t)m_ * p.H + unit_;                                                  \
+      st_pre[q] = p.gru ? p.a1[o_] : p.c_in[o_]; /* a1 is the previous state h [N,H] */            \
+      if (p.emb_proj) { /* uniform */                                                              \
+        int id_ = p.ids[m_];                                                                       \
+        id_ = min(max(id_, 0), p.V - 1);                                                           \
+        const float* ep_ = p.emb_proj + (size_t)id_ * 4 * p.H + unit_;                             \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) ep_pre[q][g] = ep_[g * p.H];                 \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) ep_pre[q][g] = 0.f;                          \
+      }                                                                                            \
+    }                                                                                              \
   }
+  if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -167,19 +190,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
   const int nk = p.K / BK;
   ICAP_BF16_LOAD(0)
   ICAP_BF16_STORE(0)
+  ICAP_STAMP(1)
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     ICAP_BF16_LOAD(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch
     __syncthreads();
-    const char* as = smem + cur * STAGE + (wm * WTM + l31) * ROW_B + half * 16;
-    const char* bs = smem + cur * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B + half * 16;
+    const char* as = smem + cur * STAGE + (wm * WTM + l31) * ROW_B;
+    const char* bs = smem + cur * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * ROW_B + ks * 32);
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * ROW_B + rd_sw[ks]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROW_B + ks * 32);
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROW_B + rd_sw[ks]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
     cur ^= 1;
   }
   __syncthreads();  // the epilogues reuse the LDS
+  ICAP_STAMP(2)
 
 #undef ICAP_BF16_LOAD
 #undef ICAP_BF16_STORE
@@ -259,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
         }
     }
   } else {
+    if constexpr (!HOIST) ICAP_BF16_CELL_OPERANDS
     // gates meet in LDS: column g*32 + u of the tile is gate g of unit n0/4 + u
     float* zs = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -298,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args p) {
       }
     }
   }
+  ICAP_STAMP(3)
 }
 
 // w[K_src][N] fp32 -> packed[n'][k_off + k] bf16, n' = n or the gate-interleaved column.
@@ -517,6 +544,13 @@ int cell_step_bf16(int gru, const float* ctx, const float* h, const float* c, co
   a.bias = bias; a.y = nullptr; a.M = N; a.N = 4 * H; a.K = C + H; a.act = ICAP_ACT_NONE;
   a.c_in = c; a.h_out = h_out; a.c_out = c_out; a.emb_proj = emb_proj; a.ids = ids; a.H = H; a.V = V;
   a.gru = gru;
+  // 64-row tiles while they fit the chip at once (three workgroups per compute unit); beyond
+  // that a second, partly filled round of workgroups costs more than 128-row tiles do (the K
+  // loop runs at the rate operands arrive from L2, and taller tiles fetch the weights half as often)
+  static const char* bm_env = getenv("ICAP_BF16_CELL_BM");  // tuning knob: "64" | "128"
+  const long long tiles64 = (long long)ceil_div(N, 64) * ceil_div(4 * H, BN);
+  const bool tall = bm_env ? atoi(bm_env) == 128 : tiles64 > 768;
+  if (tall) return launch<128, true>(a, s, "gemm_bf16_kernel<lstm,128>");
   return launch<64, true>(a, s, "gemm_bf16_kernel<lstm>");
 }
 }  // namespace
