@@ -23,7 +23,8 @@
 // Experiment builds only (-DICAP_TIMELINE): every workgroup of gemm_bf16_kernel leaves the
 // 100 MHz clock at four points of its life, read back through icap_debug_timeline.
 __device__ long long g_timeline[8192][4];
-#define ICAP_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) g_timeline[blockIdx.x][i] = wall_clock64();
+// ICAP_TIMELINE = 2 stamps only the launches with the top-k record epilogue (inside a decode)
+#define ICAP_STAMP(i) if ((ICAP_TIMELINE != 2 || TOPK > 0) && threadIdx.x == 0 && blockIdx.x < 8192) g_timeline[blockIdx.x][i] = wall_clock64();
 extern "C" int icap_debug_timeline(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(long long) * 4 * (n < 8192 ? n : 8192));
 }
@@ -156,24 +157,29 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
   constexpr int NQ = LSTM ? BM / (NT / 32) : 1;
   constexpr bool HOIST = NQ <= 8;
   float ep_pre[NQ][4], st_pre[NQ];
+  int id_pre[NQ];
+#define ICAP_BF16_CELL_IDS                                                                         \
+  _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                 \
+    const int m_ = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1); /* clamped rows are never stored */ \
+    id_pre[q] = p.emb_proj ? min(max(p.ids[m_], 0), p.V - 1) : 0;                                  \
+  }
 #define ICAP_BF16_CELL_OPERANDS                                                                    \
   {                                                                                                \
     const int unit_ = (n0 >> 2) + (tid & 31);                                                      \
     _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                               \
-      const int m_ = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1); /* clamped rows are never stored */ \
+      const int m_ = min(m0 + (tid >> 5) + q * (NT / 32), p.M - 1);                                \
       const size_t o_ = (size_t)m_ * p.H + unit_;                                                  \
       st_pre[q] = p.gru ? p.a1[o_] : p.c_in[o_]; /* a1 is the previous state h [N,H] */            \
       if (p.emb_proj) { /* uniform */                                                              \
-        int id_ = p.ids[m_];                                                                       \
-        id_ = min(max(id_, 0), p.V - 1);                                                           \
-        const float* ep_ = p.emb_proj + (size_t)id_ * 4 * p.H + unit_;                             \
+        const float* ep_ = p.emb_proj + (size_t)id_pre[q] * 4 * p.H + unit_;                       \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) ep_pre[q][g] = ep_[g * p.H];                 \
       } else {                                                                                     \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) ep_pre[q][g] = 0.f;                          \
       }                                                                                            \
     }                                                                                              \
   }
-  if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
+  // (the ids ride along with the first stage's loads, the rows they select with the second's)
+  if constexpr (LSTM && HOIST) ICAP_BF16_CELL_IDS
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
   const int nk = p.K / BK;
   ICAP_BF16_LOAD(0)
   ICAP_BF16_STORE(0)
+  if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
   ICAP_STAMP(1)
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -284,7 +291,10 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
         }
     }
   } else {
-    if constexpr (!HOIST) ICAP_BF16_CELL_OPERANDS
+    if constexpr (!HOIST) {
+      ICAP_BF16_CELL_IDS
+      ICAP_BF16_CELL_OPERANDS
+    }
     // gates meet in LDS: column g*32 + u of the tile is gate g of unit n0/4 + u
     float* zs = reinterpret_cast<float*>(smem);
 #pragma unroll

@@ -4,6 +4,8 @@ see tools/build_timeline.sh): when every workgroup started, finished its first s
 loop and its epilogue, on the 100 MHz device clock.
 
     ICAP_LIB=image_caption_amd/libicap_tl.so python tools/bf16_timeline.py lstm|fc1|dense_vocab
+    (built with ICAP_TIMELINE=2: ... bf16_timeline.py decode [overlap] - the last vocab
+    projection with its record epilogue inside a bf16 decode at B=512, beam 5)
 """
 import ctypes as C
 import os
@@ -25,7 +27,17 @@ B, W, V, H, D = 512, 5, 10000, 512, 256
 N = B * W
 g = torch.Generator(device="cpu").manual_seed(0)
 rn = lambda *s: torch.randn(*s, generator=g).to(dev)
-if which == "lstm":
+if which == "decode":
+    from image_caption_amd import synthetic
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    params = synthetic.make_params(0, F=2048, D=256, E=256, H=512, V=V)
+    cfg = CaptionConfig(B=B, W=W, L=64, F=2048, D=256, E=256, H=512, U=512, V=V, T=20, precision="bf16")
+    eng = CaptionEngine(cfg, params, device=dev)
+    eng.set_overlap(len(sys.argv) > 2 and sys.argv[2] == "overlap")
+    img = torch.from_numpy(synthetic.make_images(1, B, 64, 2048)).to(dev)
+    fn = lambda: eng.decode(img)
+    n_wg = ((N + 127) // 128) * ((V + 127) // 128)
+elif which == "lstm":
     ctx, h, c = rn(N, D), rn(N, H) * 0.3, rn(N, H) * 0.3
     kern, rec, bias = rn(D, 4 * H) * 0.05, rn(H, 4 * H) * 0.05, rn(4 * H) * 0.1
     emb_proj = rn(V, 4 * H) * 0.1
