@@ -353,11 +353,46 @@ def test_helper_functions_match_oracle(bs):
 
 # ---- fused vocab projection + beam step (no logits in memory) ----
 
+@pytest.mark.parametrize("W,boost", [(3, 6.0), (5, 6.0), (3, -6.0)])
+def test_records_step_with_eos_inside_or_outside_the_recorded_best(bs, W, boost):
+    """The eos column is scored apart from a row's recorded logits: as the best logit of its
+    half tile it leaves a hole in the middle of a record's sorted list, as the worst it is
+    not recorded at all; both must rank like the step on full logits."""
+    from image_caption_amd import ops
+    B, K, V, eos, t = 6, 64, 3000, 70, 3
+    rng = np.random.default_rng(17 + W)
+    N = B * W
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    w = (rng.standard_normal((K, V)) * 0.3).astype(np.float32)
+    bias = rng.standard_normal(V).astype(np.float32) * 0.1
+    bias[eos] += boost
+    bias[eos + 1] += abs(boost) * 0.5      # a strong neighbour in the same half tile
+    state = _random_state(rng, B, W, t)
+    lp, fin, ln = to_dev(state.log_probs), to_dev(state.finished.astype(np.uint8)), to_dev(state.lengths)
+    top_k = 3 if W <= 3 else 5
+    logits = ops.dense(to_dev(x), to_dev(w), to_dev(bias))
+    ref = ops.beam_step(logits.reshape(B, W, V), lp, fin, ln, t, eos, 1.0)
+    rec, eos_x = ops.dense_topk(to_dev(x), to_dev(w), to_dev(bias), eos, top_k)
+    got = ops.beam_step_from_records(rec, eos_x, lp, fin, ln, t, eos, 1.0, V)
+    for name, g, r in zip(["scores", "ids", "parents", "next_log_probs", "next_finished", "next_lengths"], got, ref):
+        g, r = np_of(g), np_of(r)
+        if g.dtype == np.float32:
+            with np.errstate(over="ignore"):
+                assert_close(np.maximum(g, -1e30), np.maximum(r, -1e30), rtol=2e-6, what=name)
+        else:
+            np.testing.assert_array_equal(g, r, err_msg=name)
+    if boost > 0:
+        assert (np_of(got[1]) == eos).any()    # eos does get chosen somewhere
+
+
 @pytest.mark.parametrize("B,W,K,V,t,eos", [
     (4, 3, 64, 10000, 2, 4), (3, 3, 64, 10000, 0, 4), (5, 1, 32, 1000, 3, 4), (3, 5, 96, 5000, 4, 4),
     (2, 3, 32, 132, 1, 4),        # last 128-column tile has 4 valid columns, its second half none
     (2, 2, 32, 64, 2, 70),        # eos outside the vocabulary
-    (70, 3, 64, 1028, 5, 1027)])  # several row tiles, eos in the last column
+    (70, 3, 64, 1028, 5, 1027),   # several row tiles, eos in the last column
+    (3, 4, 64, 5000, 3, 4),       # beam narrower than the records are deep
+    (2, 3, 32, 20000, 2, 4),      # five records per lane of a row's wave
+    (2, 3, 32, 40000, 2, 4)])     # more than 512 records per row: the one-workgroup form
 def test_projection_topk_records_equal_unfused_step(bs, B, W, K, V, t, eos):
     from image_caption_amd import ops
     rng = np.random.default_rng(B * 31 + W * 7 + V + t)
