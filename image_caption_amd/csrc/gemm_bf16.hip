@@ -35,6 +35,10 @@ extern "C" int icap_debug_timeline(long long* out, int n) {
 namespace icap {
 namespace {
 
+// arrivals per compute unit (index: XCC id, shader engine / array, CU id), counted up for ever:
+// only the parity of the count is used
+__device__ unsigned g_cu_arrivals[4096];
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -69,6 +73,11 @@ struct Bf16Args {
   const uint16_t* a16 = nullptr;
   int lda16 = 0;
   uint16_t* y16 = nullptr;  // [M][N], written beside y when not null
+  // Stagger of the first round of workgroups (top-k projection): of the workgroups that start
+  // together on a compute unit, every second one (by order of arrival, counted per unit) first
+  // waits stagger_ticks of the 100 MHz clock.  0: off.
+  int stagger_ticks = 0;
+  int stagger_wgs = 0;  // workgroups of the first round (blockIdx below this take part)
   int y16_blocked = 0;      // y16 in the operand-block layout of vocab_bf16.hip instead of row-major
 };
 
@@ -94,6 +103,30 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   ICAP_STAMP(0)
+  if constexpr (TOPK > 0) {
+    // The K loop of these tiles waits on operand delivery and their record epilogue on the
+    // vector unit: two workgroups that share a compute unit and start together go through
+    // both phases in lockstep and use one resource at a time.  Delaying one of them once puts
+    // the K loop of one beside the epilogue of the other; the offset carries over to the
+    // later rounds, whose workgroups start when their predecessors end.
+    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_wgs) {
+      // (the word lives in the staging buffer: a second LDS object would make the compiler
+      // drain the memory queue in front of every K stage's LDS reads)
+      volatile unsigned* s_arrival = reinterpret_cast<volatile unsigned*>(smem);
+      if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);   // HW_ID[15:8]: CU, SH, SE
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); // XCC_ID[3:0]
+        *s_arrival = atomicAdd(&g_cu_arrivals[((xcc & 15u) << 8) | (hw & 255u)], 1u);
+      }
+      __syncthreads();
+      const bool late = (*s_arrival & 1u) != 0;
+      __syncthreads();  // (the staging stores below may overwrite the word)
+      if (late) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+      }
+    }
+  }
   int tile_m, tile_n;
   tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -504,6 +537,12 @@ int dense_topk_bf16_a16(const void* x16, int blocked, const void* packed_w, cons
   if (masks) a.masks = *masks;
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, BN);
+  {
+    static const char* st_env = getenv("ICAP_BF16_STAGGER_US");  // tuning knob: microseconds, 0 = off
+    const double us = st_env ? atof(st_env) : 0.0;
+    a.stagger_ticks = (int)(us * 100.0);
+    a.stagger_wgs = 512;  // two workgroups on each of 256 compute units
+  }
   const dim3 grid(a.tiles_m * a.tiles_n), block(256);
   if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1, true>), grid, block, 0, s, a);
   else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true>), grid, block, 0, s, a);

@@ -49,6 +49,8 @@ __device__ __forceinline__ int sel_i(unsigned long long mask, int a, int b) {
 }
 
 // Inserts (v, c) into a descending list; strict '>' keeps the earlier (lower) column on ties.
+// The list is sorted, so the new entry k is the median of (entry k-1, entry k, v): one
+// v_med3_f32 per level; the columns follow with two selects per level.
 template <int TOPK>
 __device__ __forceinline__ void topk_insert(float (&tx)[TOPK], int (&tc)[TOPK], float v, int c) {
   unsigned long long gt[TOPK];
@@ -56,11 +58,11 @@ __device__ __forceinline__ void topk_insert(float (&tx)[TOPK], int (&tc)[TOPK], 
   for (int k = 0; k < TOPK; ++k) gt[k] = __builtin_amdgcn_ballot_w64(v > tx[k]);
 #pragma unroll
   for (int k = TOPK - 1; k >= 1; --k) {
-    tx[k] = sel_f(gt[k - 1], tx[k - 1], sel_f(gt[k], v, tx[k]));
     tc[k] = sel_i(gt[k - 1], tc[k - 1], sel_i(gt[k], c, tc[k]));
+    tx[k] = __builtin_amdgcn_fmed3f(tx[k - 1], tx[k], v);
   }
-  tx[0] = sel_f(gt[0], v, tx[0]);
   tc[0] = sel_i(gt[0], c, tc[0]);
+  tx[0] = __builtin_fmaxf(tx[0], v);
 }
 
 template <int TOPK, int KH>  // KH = K / 256
