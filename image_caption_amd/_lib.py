@@ -153,6 +153,8 @@ SIGNATURES = {
     "icap_engine_set_timing": ([_P, C.c_uint], C.c_int),
     "icap_engine_set_timing_every": ([_P, C.c_int], C.c_int),
     "icap_engine_set_overlap": ([_P, _I], C.c_int),
+    "icap_engine_set_fold_fc": ([_P, _I], C.c_int),
+    "icap_engine_merged_launch": ([_P], C.c_int),
     "icap_engine_set_fused_vocab": ([_P, _I], C.c_int),
     "icap_engine_fused_vocab": ([_P], C.c_int),
     "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),

@@ -136,6 +136,19 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// start tokens and the initial beam state (zeros, beam_search.py:85-98) in one launch: a
+// kernel rather than memset calls, whose nodes in a captured graph did not reliably run
+// before the first step's kernels on replays after the first
+__global__ void init_beam_state_kernel(int32_t* start_ids, int32_t start_id, float* lp, int32_t* len,
+                                       uint8_t* fin, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    start_ids[i] = start_id;
+    lp[i] = 0.f;
+    len[i] = 0;
+    fin[i] = 0;
+  }
+}
 }  // namespace
 
 }  // namespace icap
@@ -165,6 +178,7 @@ struct icap_engine {
   // bf16 mode: weights packed as bf16 [N_pad][K] (null in fp32 mode)
   enum { PK_ENC, PK_W1, PK_INIT_H, PK_INIT_C, PK_W2, PK_LSTM, PK_LSTM_EMB, PK_FC1, PK_FC2, PK_COUNT };
   void* pk[PK_COUNT] = {};
+  void* pk_fold = nullptr;  // split mode: the folded fc1 . fc2 kernel, packed like pk[PK_FC2]
   // fused vocab projection + beam step: per-row top-k records instead of the [N,V] logits
   int topk = 0;       // 0: unfused (logits buffer + beam_step kernels)
   int topk_able = 0;  // the top_k the fused path would use for this shape (0: not served)
@@ -183,6 +197,14 @@ struct icap_engine {
   int32_t* len2 = nullptr;
   long wide_rescues_forced = 0;  // test hook: raise the flag at every step
   bool a16 = true;               // bf16 mode: bf16 hand-over between fc1 and the projection (ICAP_BF16_A16=0: off)
+  // fc1 and fc2 have no activation between them (decoder/lstm_recurrent_decoder.py:41-42,
+  // 106-112; the dropout is the identity at inference), so logits = h . (W1 . W2) + (b1 . W2 + b2):
+  // the product of the two kernels and the combined bias are formed once per engine (sums in
+  // double precision, rounded to f32 once) and the step projects the LSTM output directly -
+  // one launch per step less.  fp32 and split mode; ICAP_FOLD_FC=0 / icap_engine_set_fold_fc
+  // keep the two-step form.
+  float *w12 = nullptr, *b12 = nullptr;
+  bool fold = false;
   // side stream: the next step's attention runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr, ev_gate = nullptr;
@@ -204,6 +226,25 @@ struct icap_engine {
 
 namespace icap {
 namespace {
+
+// w12[k][v] = sum_j w1[k][j] * w2[j][v], b12[v] = sum_j b1[j] * w2[j][v] + b2[v] (row k == H),
+// accumulated in double precision.  One thread per (k, v); a workgroup covers 256 columns of
+// one row, so w1[k][j] is a broadcast and w2[j][v] a coalesced read.
+__global__ __launch_bounds__(256) void fold_fc_kernel(const float* __restrict__ w1,
+                                                      const float* __restrict__ b1,
+                                                      const float* __restrict__ w2,
+                                                      const float* __restrict__ b2,
+                                                      float* __restrict__ w12,
+                                                      float* __restrict__ b12, int H, int V) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;  // k == H: the bias row
+  if (v >= V) return;
+  const float* left = k < H ? w1 + (size_t)k * H : b1;
+  double acc = 0.0;
+  for (int j = 0; j < H; ++j) acc += (double)left[j] * (double)w2[(size_t)j * V + v];
+  if (k < H) w12[(size_t)k * V + v] = (float)acc;
+  else b12[v] = (float)(acc + (double)b2[v]);
+}
 
 struct Carver {
   size_t off = 0;
@@ -275,14 +316,16 @@ struct Timed {
   } while (0)
 
 // y = act(x . W + b) in the engine's precision; `which` names the packed copy of `wf`.
+// packed: the packed form of wf when it is not e->pk[which] (the folded output kernel)
 int engine_dense(const icap_engine* e, int which, const float* x, const float* wf, const float* bias,
-                 float* y, int M, int K, int N, int act, hipStream_t s) {
+                 float* y, int M, int K, int N, int act, hipStream_t s, const void* packed = nullptr) {
+  const void* pkw = packed ? packed : e->pk[which];
   if (e->cfg.precision == ICAP_PRECISION_BF16)
-    return dense_bf16(x, e->pk[which], bias, y, M, K, N, act, s);
+    return dense_bf16(x, pkw, bias, y, M, K, N, act, s);
   // split mode pays on the large products; the small projections (a few hundred 64x64
   // tiles) are latency-bound and stay on the exact-f32 kernels
   if (e->cfg.precision == ICAP_PRECISION_F32_SPLIT && (long long)ceil_div(M, 128) * ceil_div(N, 128) >= 256)
-    return dense_split(x, e->pk[which], bias, y, M, K, N, act, s);
+    return dense_split(x, pkw, bias, y, M, K, N, act, s);
   return dense_f32(x, wf, bias, y, M, K, N, act, s);
 }
 
@@ -344,14 +387,13 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(expand_rows_f32(e->init_c, e->c, c.B, c.W, c.H, c.reset_state_from_feat,
                                c.tile_mode, s));
     }
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, e->start_ids,
-                       c.start_id, N);
-    ICAP_LAUNCH_CHECK("fill_i32_kernel");
-    // initial beam state: zeros (beam_search.py:85-98)
-    ICAP_HIP(hipMemsetAsync(e->lp, 0, sizeof(float) * N, s));
-    ICAP_HIP(hipMemsetAsync(e->len, 0, sizeof(int32_t) * N, s));
-    ICAP_HIP(hipMemsetAsync(e->fin, 0, N, s));
-    if (wide) ICAP_HIP(hipMemsetAsync(e->flags, 0, 256, s));
+    hipLaunchKernelGGL(init_beam_state_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, e->start_ids,
+                       c.start_id, e->lp, e->len, e->fin, N);
+    ICAP_LAUNCH_CHECK("init_beam_state_kernel");
+    if (wide) {
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, e->flags, 0, 64);
+      ICAP_LAUNCH_CHECK("fill_i32_kernel");
+    }
   }
   // The beam step inside the projection's launch: exact-f32 fused path without logit masks
   const bool beam_in_launch = e->beam_in_launch && topk != 0 && !wide && !masks.any() &&
@@ -360,8 +402,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   unsigned* done1 = e->tile_rows_done + e->tile_rows;
   int* beam_err = reinterpret_cast<int*>(e->tile_rows_done + 2 * e->tile_rows);
   unsigned launches1 = 0;
-  if (beam_in_launch)
-    ICAP_HIP(hipMemsetAsync(e->tile_rows_done, 0, sizeof(unsigned) * (2 * e->tile_rows + 1), s));
+  if (beam_in_launch) {
+    const int words = 2 * e->tile_rows + 1;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(words, 256)), dim3(256), 0, s,
+                       reinterpret_cast<int32_t*>(e->tile_rows_done), 0, words);
+    ICAP_LAUNCH_CHECK("fill_i32_kernel");
+  }
 
   const int stride_g = c.tile_mode == ICAP_TILE_REPEAT ? c.W : 1;
   const int stride_k = c.tile_mode == ICAP_TILE_REPEAT ? 1 : c.B;
@@ -420,12 +466,24 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // Exact-f32 fused path: query_{t+1} + attention_{t+1} are the first workgroups of the
   // vocab_t launch instead (dense_topk_attention_f32), everything on the caller's stream:
   //   main: lstm_t -> fc1_t -> [attention_{t+1} | vocab_t] -> beam_t -> lstm_{t+1} ...
-  const bool merged = e->merged && e->overlap && topk != 0 && !wide;
+  // (a decode that is being captured into a graph keeps the fork / join schedule: after a
+  // capture of the merged schedule, side-stream decodes of other engines of the process were
+  // seen to hang on their event waits)
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capture);
+  const bool merged = e->merged && e->overlap && topk != 0 && !wide &&
+                      capture == hipStreamCaptureStatusNone;
   const bool side = e->overlap && !merged;
   const int att_blocks = e->side_att_wgs > 0 ? e->side_att_wgs : c.B;
+  // the output projection's operands: the folded kernel applied to the LSTM output, or fc2
+  // applied to fc1's output
+  const bool fold = e->fold && e->w12 != nullptr;
+  const float* vw = fold ? e->w12 : w.fc2_kernel;
+  const float* vb = fold ? e->b12 : w.fc2_bias;
+  const void* vpk = fold ? e->pk_fold : e->pk[icap_engine::PK_FC2];
   auto vocab_with_attention = [&](const float* x, int lda, int rows, const LogitMasks* mk,
                                   const float* state) -> int {
-    return dense_topk_attention_f32(x, lda, w.fc2_kernel, w.fc2_bias, rows, c.H, c.V, c.eos_id,
+    return dense_topk_attention_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id,
                                     topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
                                     e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
                                     w.att_w2_kernel, w.att_w2_bias, e->ctx, c.B, c.W, stride_g,
@@ -477,14 +535,16 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       // Time 0 ranks the candidates of beam 0 only (beam_search.py:451-455), so fc1 and the
       // vocab projection run on every W-th row (row stride W*H) and write one record row per
       // image; the recurrent state of all rows was still advanced above.
-      {
+      if (!fold) {
         Timed tm(e, ICAP_K_FC1, s);
         ICAP_TRY(dense_f32_strided(e->h[cur], c.W * c.H, w.fc1_kernel, w.fc1_bias, e->fc1o, c.B, c.H,
                                    c.H, ICAP_ACT_NONE, s));
       }
+      const float* x0 = fold ? e->h[cur] : e->fc1o;  // beam 0's rows
+      const int lda0 = fold ? c.W * c.H : c.H;
       if (beam_in_launch) {
         Timed tm(e, ICAP_K_VOCAB, s);
-        ICAP_TRY(dense_topk_beam_f32(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V, c.eos_id,
+        ICAP_TRY(dense_topk_beam_f32(x0, lda0, vw, vb, c.B, c.H, c.V, c.eos_id,
                                      topk, e->rec, e->eos_x, lp_in, fin, len, 0,
                                      c.length_penalty_weight, e->hist_scores, e->hist_ids,
                                      e->hist_parents, e->hist_lp, fin, len, c.B, c.W, 1, done0, 1,
@@ -495,9 +555,9 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       {
         Timed tm(e, ICAP_K_VOCAB, s);
         if (merged && t + 1 < c.T)
-          ICAP_TRY(vocab_with_attention(e->fc1o, c.H, c.B, nullptr, gru ? e->h[cur] : e->c));
+          ICAP_TRY(vocab_with_attention(x0, lda0, c.B, nullptr, gru ? e->h[cur] : e->c));
         else
-          ICAP_TRY(dense_topk_f32_strided(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, c.B, c.H, c.V,
+          ICAP_TRY(dense_topk_f32_strided(x0, lda0, vw, vb, c.B, c.H, c.V,
                                           c.eos_id, topk, e->rec, e->eos_x, nullptr, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
@@ -514,8 +574,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         // behind it, switched off on the device unless the flag is up: the same step on the
         // full logits of beam 0 ([B,1,V]; the state before step 0 is all zeros, so its first
         // B entries serve as the [B,1] state)
-        ICAP_TRY(dense_f32_flagged(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, e->logits, c.B, c.H, c.V,
-                                   flag, s));
+        ICAP_TRY(dense_f32_flagged(x0, lda0, vw, vb, e->logits, c.B, c.H, c.V, flag, s));
         ICAP_TRY(beam_step_rows_f32(e->logits, lp_in, fin, len, 0, 0, c.eos_id,
                                     c.length_penalty_weight, 0, e->hist_scores, e->hist_ids,
                                     e->hist_parents, e->hist_lp, fin_o, len_o, c.B, 1, c.W, c.V,
@@ -534,7 +593,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     // that (the values the projection's own staging conversion would produce)
     const bool a16 = topk != 0 && c.precision == ICAP_PRECISION_BF16 && e->a16;
     const int a16_blocked = a16 && dense_topk_bf16_a16_blocked(N, c.H, c.V, topk) ? 1 : 0;
-    {  // K7: fc1
+    const float* vx = fold ? e->h[cur] : e->fc1o;  // [N,H]
+    if (!fold) {  // K7: fc1
       Timed tm(e, ICAP_K_FC1, s);
       if (a16)
         ICAP_TRY(dense_bf16_dual(e->h[cur], e->pk[icap_engine::PK_FC1], w.fc1_bias, e->fc1o, e->fc1o16,
@@ -549,7 +609,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
         ICAP_HIP(hipEventRecord(e->ev_gate, s));
       if (beam_in_launch && c.precision == ICAP_PRECISION_FP32) {
         Timed tm(e, ICAP_K_VOCAB, s);
-        ICAP_TRY(dense_topk_beam_f32(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
+        ICAP_TRY(dense_topk_beam_f32(vx, c.H, vw, vb, N, c.H, c.V, c.eos_id,
                                      topk, e->rec, e->eos_x, lp_in, fin, len, bs_time,
                                      c.length_penalty_weight, e->hist_scores + (size_t)t * N,
                                      e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
@@ -567,12 +627,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           ICAP_TRY(dense_topk_bf16(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
                                    c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (c.precision == ICAP_PRECISION_F32_SPLIT)
-          ICAP_TRY(dense_topk_split(e->fc1o, e->pk[icap_engine::PK_FC2], w.fc2_bias, N, c.H, c.V,
+          ICAP_TRY(dense_topk_split(vx, vpk, vb, N, c.H, c.V,
                                     c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (merged && t + 1 < c.T)
-          ICAP_TRY(vocab_with_attention(e->fc1o, c.H, N, mk, gru ? e->h[cur] : e->c));
+          ICAP_TRY(vocab_with_attention(vx, c.H, N, mk, gru ? e->h[cur] : e->c));
         else
-          ICAP_TRY(dense_topk_f32(e->fc1o, w.fc2_kernel, w.fc2_bias, N, c.H, c.V, c.eos_id,
+          ICAP_TRY(dense_topk_f32(vx, vw, vb, N, c.H, c.V, c.eos_id,
                                   topk, e->rec, e->eos_x, mk, s));
       }
       if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
@@ -588,8 +648,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
           ICAP_LAUNCH_CHECK("fill_i32_kernel");
         }
         // behind it, switched off on the device unless the flag is up: the unfused step
-        ICAP_TRY(dense_f32_flagged(e->fc1o, c.H, w.fc2_kernel, w.fc2_bias, e->logits, N, c.H, c.V,
-                                   flag, s));
+        ICAP_TRY(dense_f32_flagged(vx, c.H, vw, vb, e->logits, N, c.H, c.V, flag, s));
         ICAP_TRY(beam_step_rows_f32(e->logits, lp_in, fin, len, bs_time, 0, c.eos_id,
                                     c.length_penalty_weight, 0, e->hist_scores + (size_t)t * N,
                                     e->hist_ids + (size_t)t * N, e->hist_parents + (size_t)t * N,
@@ -609,8 +668,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     }
     {  // K8: vocab projection
       Timed tm(e, ICAP_K_VOCAB, s);
-      ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, e->fc1o, w.fc2_kernel, w.fc2_bias, e->logits, N,
-                            c.H, c.V, ICAP_ACT_NONE, s));
+      ICAP_TRY(engine_dense(e, icap_engine::PK_FC2, vx, vw, vb, e->logits, N, c.H, c.V, ICAP_ACT_NONE,
+                            s, vpk));
       if (mk) ICAP_TRY(logit_masks_f32(e->logits, N, c.V, masks, s));
     }
     if (t + 1 < c.T && !e->overlap) ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
@@ -923,6 +982,9 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                o_bws = cv.take<char>(beam_step_workspace_bytes(c.B, c.W)),
                o_ep = cv.take<float>((size_t)c.V * 4 * c.H);
   const size_t o_rl = cv.take<int32_t>(N);
+  const bool fold_able = c.precision == ICAP_PRECISION_FP32 || c.precision == ICAP_PRECISION_F32_SPLIT;
+  const size_t o_w12 = cv.take<float>(fold_able ? (size_t)c.H * c.V : 0),
+               o_b12 = cv.take<float>(fold_able ? (size_t)c.V : 0);
   const size_t o_fin2 = cv.take<uint8_t>(N), o_len2 = cv.take<int32_t>(N), o_flags = cv.take<char>(256);
   e->tile_rows = ceil_div((int)N, 128);
   const size_t o_trd = cv.take<unsigned>(2 * e->tile_rows + 1);
@@ -979,6 +1041,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   if (c.precision == ICAP_PRECISION_F32_SPLIT)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i)
       o_pk[i] = cv.take<char>(packed_split_bytes(pk_dims[i][0], pk_dims[i][1]));
+  const size_t o_pkf =
+      cv.take<char>(c.precision == ICAP_PRECISION_F32_SPLIT ? packed_split_bytes(c.H, c.V) : 0);
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
@@ -1012,10 +1076,19 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
                                 : (c.precision == ICAP_PRECISION_BF16 ? 0 : prop.multiProcessorCount);
   }
   {
-    // opt-in (ICAP_MERGED=1, read when the engine is created): measured 1 % slower than the
-    // side stream at the headline shape (the attention workgroups take a projection slot each)
+    // The next step's query + attention inside the projection's launch.  With the folded
+    // output kernel nothing stands between the cell kernel and the projection any more, so on
+    // the side stream the attention (behind its query kernel) would always arrive after the
+    // projection has taken every slot; in the projection's own launch its workgroups come
+    // first by construction and the query kernel, two event dependencies and the launch race
+    // are gone: 107.8k against 100.8k captions/s at the headline shape (with fc1 as a launch
+    // of its own the two schedules are equal, 101.6k against 101.4k).  ICAP_MERGED=0|1
+    // overrides (read when the engine is created).
     const char* merged_env = getenv("ICAP_MERGED");
-    e->merged = merged_env && merged_env[0] == '1' && c.precision == ICAP_PRECISION_FP32 &&
+    const char* fold_env0 = getenv("ICAP_FOLD_FC");
+    const bool fold_on = fold_able && !(fold_env0 && fold_env0[0] == '0');
+    const bool want = merged_env ? merged_env[0] == '1' : fold_on;
+    e->merged = want && c.precision == ICAP_PRECISION_FP32 &&
                 e->topk_able != 0 &&
                 dense_topk_attention_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able) &&
                 aligned16(weights->att_v_kernel) && aligned16(weights->att_w2_kernel);
@@ -1046,6 +1119,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->beam_ws_bytes = beam_step_workspace_bytes(c.B, c.W);
   e->emb_proj = (float*)(b + o_ep);
   e->row_len = (int32_t*)(b + o_rl);
+  if (fold_able) {
+    e->w12 = (float*)(b + o_w12);
+    e->b12 = (float*)(b + o_b12);
+    const char* fold_env = getenv("ICAP_FOLD_FC");  // tuning knob, read per engine
+    e->fold = !(fold_env && fold_env[0] == '0');
+  }
   e->fin2 = (uint8_t*)(b + o_fin2);
   e->len2 = (int32_t*)(b + o_len2);
   e->flags = (int*)(b + o_flags);
@@ -1076,6 +1155,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->eos_x = (float*)(b + o_eosx);
   if (c.precision != ICAP_PRECISION_FP32)
     for (int i = 0; i < icap_engine::PK_COUNT; ++i) e->pk[i] = b + o_pk[i];
+  if (c.precision == ICAP_PRECISION_F32_SPLIT) e->pk_fold = b + o_pkf;
   {
     const int rc = icap_engine_refresh_weights(e, nullptr);
     if (rc != ICAP_OK) {
@@ -1102,6 +1182,11 @@ int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
     ICAP_TRY(gru_pack_f32(w.lstm_kernel, w.lstm_recurrent_kernel, w.lstm_bias, e->gru_k4, e->gru_r4,
                           e->gru_b4, c.D + c.E, c.H, s));
   const float* emb_rows = e->cell_kernel + (size_t)c.D * 4 * c.H;  // kernel rows of the embedding
+  if (e->w12) {
+    hipLaunchKernelGGL(fold_fc_kernel, dim3(ceil_div(c.V, 256), c.H + 1), dim3(256), 0, s, w.fc1_kernel,
+                       w.fc1_bias, w.fc2_kernel, w.fc2_bias, e->w12, e->b12, c.H, c.V);
+    ICAP_LAUNCH_CHECK("fold_fc_kernel");
+  }
   if (c.precision != ICAP_PRECISION_FP32) {
     typedef icap_engine E;
     auto pack = c.precision == ICAP_PRECISION_BF16 ? pack_weight_bf16 : pack_weight_split;
@@ -1116,6 +1201,7 @@ int icap_engine_refresh_weights(icap_engine* e, icap_stream_t stream) {
     ICAP_TRY(pack(emb_rows, e->pk[E::PK_LSTM_EMB], c.E, 4 * c.H, 0, c.E, 0, s));
     ICAP_TRY(pack(w.fc1_kernel, e->pk[E::PK_FC1], c.H, c.H, 0, c.H, 0, s));
     ICAP_TRY(pack(w.fc2_kernel, e->pk[E::PK_FC2], c.H, c.V, 0, c.H, 0, s));
+    if (e->w12) ICAP_TRY(pack(e->w12, e->pk_fold, c.H, c.V, 0, c.H, 0, s));
   }
   // emb_proj[v] = embedding[v] . lstm_kernel[D:D+E]: the part of the LSTM gates that
   // depends only on the input token, hoisted out of the step loop
@@ -1240,6 +1326,18 @@ int icap_engine_fused_vocab(const icap_engine* e) { return e && e->topk ? 1 : 0;
 int icap_engine_set_overlap(icap_engine* e, int on) {
   ICAP_REQUIRE(e, "icap_engine_set_overlap: null engine");
   e->overlap = on != 0;
+  return ICAP_OK;
+}
+
+int icap_engine_merged_launch(const icap_engine* e) {
+  return e && e->merged && e->overlap && e->topk != 0 && !e->wide ? 1 : 0;
+}
+
+int icap_engine_set_fold_fc(icap_engine* e, int on) {
+  ICAP_REQUIRE(e, "icap_engine_set_fold_fc: null engine");
+  if (on && !e->w12)
+    return fail(ICAP_ERR_UNSUPPORTED, "icap_engine_set_fold_fc: the folded output kernel serves fp32 and split mode");
+  e->fold = on != 0;
   return ICAP_OK;
 }
 

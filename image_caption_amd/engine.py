@@ -232,6 +232,16 @@ class CaptionEngine:
         """Select the fused (default where served) or the unfused projection + beam step."""
         _lib.call("icap_engine_set_fused_vocab", self._handle, 1 if on else 0)
 
+    @property
+    def merged_launch(self):
+        """True when the next step's query + attention ride in the vocab projection's launch."""
+        return bool(_lib.load().icap_engine_merged_launch(self._handle))
+
+    def set_fold_fc(self, on):
+        """True (default in fp32 / split mode): project the cell output with the folded
+        fc1 . fc2 kernel; False: the reference's two products."""
+        _lib.call("icap_engine_set_fold_fc", self._handle, 1 if on else 0)
+
     def set_overlap(self, on):
         """False keeps every launch on the caller's stream (no side-stream attention)."""
         _lib.call("icap_engine_set_overlap", self._handle, 1 if on else 0)

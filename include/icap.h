@@ -474,6 +474,20 @@ int icap_engine_set_timing_every(icap_engine* engine, int n);
  * identical either way.  No counterpart in the reference (its loop is sequential,
  * recurrent_example.py:517-558). */
 int icap_engine_set_overlap(icap_engine* engine, int on);
+/* fc1 and fc2 of the decoder have no activation between them
+ * (decoder/lstm_recurrent_decoder.py:41-42,106-112; the dropout between them is the identity at
+ * inference), so logits = h . (W1 . W2) + (b1 . W2 + b2).  In fp32 and split mode the engine
+ * forms the folded kernel and bias once (icap_engine_create / icap_engine_refresh_weights;
+ * sums in double precision, rounded to float32 once) and projects the cell output directly,
+ * which removes one launch per decode step; on == 0 keeps the reference's two products
+ * (default: folded, or the two products with ICAP_FOLD_FC=0 in the environment when the
+ * engine is created).  The logits of the two forms differ by float32 rounding only (both
+ * within the 1e-5 bar of the oracle).  ICAP_ERR_UNSUPPORTED in bf16 mode with on != 0. */
+int icap_engine_set_fold_fc(icap_engine* engine, int on);
+/* 1 when the engine carries the next step's query projection and attention in the first
+ * workgroups of the vocab projection's launch (fp32 fused path with the folded output kernel;
+ * ICAP_MERGED=0|1 in the environment at creation overrides), 0 when they run on the side stream. */
+int icap_engine_merged_launch(const icap_engine* engine);
 /* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
  * icap_beam_step_from_records_f32; in bf16 mode the bf16 projection writes the same
  * records) whenever its shape is served: for fp32 V % 4 == 0, H % 32 == 0 (beams wider than 5

@@ -140,14 +140,20 @@ FUSABLE = dict(F=48, D=32, E=24, H=64, V=200)     # H % 32 == 0, V % 4 == 0: the
 
 
 @pytest.mark.parametrize("W", [1, 2, 3, 5])
-@pytest.mark.parametrize("schedule", ["side", "single_stream", "merged_launch", "side_fused_query",
+@pytest.mark.parametrize("schedule", ["default", "side", "single_stream", "two_products",
+                                      "two_products_merged", "folded_at_run_time", "side_fused_query",
                                       "beam_in_launch"])
 def test_decode_schedules(monkeypatch, schedule, W):
-    """The default side-stream schedule, everything on one stream, and the opt-in forms (next
-    step's query + attention inside the vocab projection's launch; query folded into the side
-    stream's attention launch; the beam step inside the projection's launch) against the
-    oracle."""
-    if schedule == "merged_launch":
+    """The default schedule (folded output kernel, next step's query + attention inside the
+    vocab projection's launch), the side-stream schedule, everything on one stream, the
+    reference's two output products (fc1, then fc2) on either schedule, and the opt-in forms
+    (query folded into the side stream's attention launch; the beam step inside the
+    projection's launch) against the oracle."""
+    if schedule in ("side", "side_fused_query"):
+        monkeypatch.setenv("ICAP_MERGED", "0")
+    if schedule in ("two_products", "two_products_merged", "folded_at_run_time"):
+        monkeypatch.setenv("ICAP_FOLD_FC", "0")
+    if schedule == "two_products_merged":
         monkeypatch.setenv("ICAP_MERGED", "1")
     if schedule == "beam_in_launch":
         monkeypatch.setenv("ICAP_BEAM_IN_LAUNCH", "1")
@@ -158,6 +164,9 @@ def test_decode_schedules(monkeypatch, schedule, W):
         assert eng.fused_vocab
         if schedule == "single_stream":
             eng.set_overlap(False)
+        if schedule == "folded_at_run_time":
+            eng.set_fold_fc(True)
+        assert eng.merged_launch == (schedule in ("default", "two_products_merged", "beam_in_launch"))
 
     for tile_mode in ("reference", "repeat"):
         nbad, _ = _compare_decode({}, FUSABLE, seed=11 + W, B=7, L=6, T=6, W=W, tile_mode=tile_mode,
@@ -529,6 +538,9 @@ def test_weights_changed_in_place_are_picked_up_by_cached_engines():
     q["fc3_bias"] = np.array([1.5], np.float32)
     q["att_V_bias"] = np.array([-0.4], np.float32)     # (softmax is shift invariant: a no-op check)
     q["fc2_bias"] = (p["fc2_bias"] + rng.normal(0, 1.0, p["fc2_bias"].shape)).astype(np.float32)
+    # (fc1 and fc2 feed the engine's folded output kernel, another derived buffer)
+    q["fc1_kernel"] = (p["fc1_kernel"] * 0.8 + rng.normal(0, 0.02, p["fc1_kernel"].shape)).astype(np.float32)
+    dec.fc1.kernel.copy_(to_dev(q["fc1_kernel"]))
     dec.embedding_layer.table.copy_(to_dev(q["embedding"]))
     dec.lstm.kernel.copy_(to_dev(q["lstm_kernel"]))
     dec.fc3.bias.copy_(to_dev(q["fc3_bias"]))
@@ -546,7 +558,7 @@ def test_weights_changed_in_place_are_picked_up_by_cached_engines():
         eng = CaptionEngine(cfg, p, device=dev())
         a = np_of(eng.decode(to_dev(img))[0]).copy()
         for name, field in (("embedding", "embedding"), ("lstm_kernel", "lstm_kernel"),
-                            ("fc3_bias", "fc3_bias"), ("fc2_bias", "fc2_bias")):
+                            ("fc3_bias", "fc3_bias"), ("fc2_bias", "fc2_bias"), ("fc1_kernel", "fc1_kernel")):
             eng.weights[field].detach().view(-1).data.copy_(to_dev(q[name]).view(-1))
         eng._versions = eng._weight_versions()         # as if the write had bypassed torch
         eng.refresh_weights()
