@@ -91,7 +91,9 @@ __device__ __forceinline__ void att_load_batch(float4 (&x)[LB][CH], const float*
 
 // RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.  The
 // workgroup (NT threads) walks work items first, first + stride, ...
-template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH>
+// QCOH: the queries were written by other workgroups of the same launch with device-scope
+// stores and are read with device scope (VEC only).
+template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool QCOH = false>
 __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int first, int stride) {
   constexpr int WAVES = NT / 64;
   float* s_w = reinterpret_cast<float*>(smem);
@@ -141,7 +143,20 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
       const int n = g * p.stride_g + k * p.stride_k;
       const float* qrow = p.q + (size_t)n * p.U;
 #pragma unroll
-      for (int ch = 0; ch < UCH; ++ch) q4[r][ch] = att_ld4<VEC>(qrow, ch * 256 + lane * 4, p.U);
+      for (int ch = 0; ch < UCH; ++ch) {
+        if constexpr (QCOH) {
+          const int i = ch * 256 + lane * 4;
+          const bool ok = i + 3 < p.U;
+          const unsigned long long* s2 = reinterpret_cast<const unsigned long long*>(qrow + (ok ? i : 0));
+          const unsigned long long lo = __hip_atomic_load(s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load(s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q4[r][ch] = ok ? make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          q4[r][ch] = att_ld4<VEC>(qrow, ch * 256 + lane * 4, p.U);
+        }
+      }
     }
     auto score_location = [&](const float4 (&x)[UCH], int l) {
       float a[RB];
@@ -177,7 +192,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
     if constexpr (VEC) {
       // two register sets of LB locations each: the next set's loads are in flight while the
       // current one is scored (same locations per wave and same order as the plain loop)
-      constexpr int LB = (RB * UCH <= 6) ? 4 : 2;
+      constexpr int LB = (RB * UCH <= 6 && NT <= 256) ? 4 : 2;  // (512-thread form: inside a projection launch, 128 registers)
       constexpr int STEP = WAVES * LB;
       int off[UCH];
 #pragma unroll
@@ -315,6 +330,9 @@ inline size_t attention_fq_lds_floats(int nt, int R, int ip, int L, int U, int D
   return sw + ATT_MAX_ROWS + part + rows * U;
 }
 
+#ifndef ICAP_ATT_STAMP
+#define ICAP_ATT_STAMP(i)  // (experiment builds define it to record the device clock)
+#endif
 #ifndef ICAP_FQ_LB512
 #define ICAP_FQ_LB512 4
 #endif
@@ -361,7 +379,11 @@ __device__ __forceinline__ void attention_fq_body(const AttArgs& p, char* smem, 
       const int kgi = tid / quads, quad = tid - kgi * quads;
       const bool active = kgi < KG;
       const int hk = (((p.H + KG - 1) / KG) + 7) & ~7;  // k values per slice
+#ifdef ICAP_EXPERIMENT_SKIP_QUERY  // (timing experiment only: the query product is not computed)
+      const int k_lo = 0, k_hi = 0;
+#else
       const int k_lo = active ? min(kgi * hk, p.H) : 0, k_hi = active ? min(k_lo + hk, p.H) : 0;
+#endif
       float4 acc[ROWS];
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -412,7 +434,9 @@ __device__ __forceinline__ void attention_fq_body(const AttArgs& p, char* smem, 
       __syncthreads();
     }
 
+    ICAP_ATT_STAMP(2)
     for (int it = 0; it < IP; ++it) {
+      ICAP_ATT_STAMP(3 + it)
       const int g = g0 + it * stride;
       if (g >= p.G) break;  // uniform
       const float* pf_g = p.pf + (size_t)g * p.L * p.U;
@@ -469,6 +493,7 @@ __device__ __forceinline__ void attention_fq_body(const AttArgs& p, char* smem, 
         }
       }
       __syncthreads();
+      if (it == 0) { ICAP_ATT_STAMP(5) }
 
       // ---- phase 2: softmax over l, one wave per row ----
       for (int k = wave; k < RB; k += WAVES) {

@@ -90,6 +90,13 @@ int dense_topk_attention_f32(const float*, int, const float*, const float*, int,
                              const float*, float, const float*, const float*, float, const float*,
                              const float*, float*, int, int, int, int, int, int, int, int, int,
                              hipStream_t);
+bool dense_topk_attq_supported(int R, int L, int U, int D, int H, int top_k);
+int dense_topk_attq_tiles(int rows, int U);
+int dense_topk_attq_f32(const float*, int, const float*, const float*, int, int, int, int, int,
+                        float*, float*, const LogitMasks*, const float*, const float*,
+                        const float*, float, const float*, const float*, float, const float*,
+                        const float*, float*, float*, int, int, int, int, int, int, int, int, int,
+                        unsigned*, unsigned, int*, hipStream_t);
 bool attention_fq_supported(int R, int L, int U, int D, int H);
 int attention_fq_f32(const float*, const float*, const float*, float, const float*, const float*,
                      float, const float*, const float*, float*, int, int, int, int, int, int, int,
@@ -140,8 +147,9 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
 // kernel rather than memset calls, whose nodes in a captured graph did not reliably run
 // before the first step's kernels on replays after the first
 __global__ void init_beam_state_kernel(int32_t* start_ids, int32_t start_id, float* lp, int32_t* len,
-                                       uint8_t* fin, int n) {
+                                       uint8_t* fin, int n, unsigned* words2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2) words2[i] = 0u;  // the query-tile counter and its error word
   if (i < n) {
     start_ids[i] = start_id;
     lp[i] = 0.f;
@@ -213,6 +221,10 @@ struct icap_engine {
   // exact-f32 fused path: the next step's query + attention ride in the first workgroups of
   // the vocab projection's launch (one stream, no events) instead of on the side stream
   bool merged = false;
+  // ... with the query projection as matrix tiles of that launch (dense_topk_attq_f32): a
+  // counter of finished query tiles (zeroed per decode) and an error word behind it
+  bool qtiles = false;
+  unsigned* q_done = nullptr;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   unsigned timing_mask = 0;  // the caller's selection; `timing` is it or 0, per decode call
@@ -388,7 +400,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                                c.tile_mode, s));
     }
     hipLaunchKernelGGL(init_beam_state_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, e->start_ids,
-                       c.start_id, e->lp, e->len, e->fin, N);
+                       c.start_id, e->lp, e->len, e->fin, N, e->q_done);
     ICAP_LAUNCH_CHECK("init_beam_state_kernel");
     if (wide) {
       hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, e->flags, 0, 64);
@@ -481,8 +493,17 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const float* vw = fold ? e->w12 : w.fc2_kernel;
   const float* vb = fold ? e->b12 : w.fc2_bias;
   const void* vpk = fold ? e->pk_fold : e->pk[icap_engine::PK_FC2];
+  unsigned q_launches = 0;
+  const int nq_tiles = dense_topk_attq_tiles((int)N, c.U);
   auto vocab_with_attention = [&](const float* x, int lda, int rows, const LogitMasks* mk,
                                   const float* state) -> int {
+    if (e->qtiles)
+      return dense_topk_attq_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk,
+                                 e->pf, features, w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel,
+                                 e->fc3_bias, w.att_w2_kernel, w.att_w2_bias, e->q, e->ctx, c.B, c.W,
+                                 stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
+                                 ++q_launches * (unsigned)nq_tiles,
+                                 reinterpret_cast<int*>(e->q_done + 1), s);
     return dense_topk_attention_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id,
                                     topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
                                     e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
@@ -688,7 +709,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     // (a beam step inside a projection launch that could not be taken invalidates the result)
     ICAP_TRY(backtrack_guarded(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N,
                                fin, tokens, nullptr, best_score, c.T, c.B, c.W,
-                               beam_in_launch ? beam_err : nullptr, s));
+                               beam_in_launch ? beam_err
+                               : (merged && e->qtiles) ? reinterpret_cast<int*>(e->q_done + 1) : nullptr, s));
   }
   return ICAP_OK;
 }
@@ -988,6 +1010,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   const size_t o_fin2 = cv.take<uint8_t>(N), o_len2 = cv.take<int32_t>(N), o_flags = cv.take<char>(256);
   e->tile_rows = ceil_div((int)N, 128);
   const size_t o_trd = cv.take<unsigned>(2 * e->tile_rows + 1);
+  const size_t o_qd = cv.take<unsigned>(64);
   const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
       cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
   const bool gru = c.cell == ICAP_CELL_GRU;
@@ -1086,12 +1109,17 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     // overrides (read when the engine is created).
     const char* merged_env = getenv("ICAP_MERGED");
     const char* fold_env0 = getenv("ICAP_FOLD_FC");
-    const bool fold_on = fold_able && !(fold_env0 && fold_env0[0] == '0');
+    const bool fold_on = fold_able && (fold_env0 ? fold_env0[0] != '0' : c.precision == ICAP_PRECISION_FP32);
     const bool want = merged_env ? merged_env[0] == '1' : fold_on;
     e->merged = want && c.precision == ICAP_PRECISION_FP32 &&
                 e->topk_able != 0 &&
                 dense_topk_attention_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able) &&
                 aligned16(weights->att_v_kernel) && aligned16(weights->att_w2_kernel);
+    // the query projection as tiles of the same launch (ICAP_MERGED_QTILES=0: inside every
+    // attention workgroup instead)
+    const char* qt_env = getenv("ICAP_MERGED_QTILES");
+    e->qtiles = e->merged && !(qt_env && qt_env[0] == '0') &&
+                dense_topk_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able);
   }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);
@@ -1122,13 +1150,18 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   if (fold_able) {
     e->w12 = (float*)(b + o_w12);
     e->b12 = (float*)(b + o_b12);
+    // default: exact-f32 mode.  Split mode keeps the two products unless asked to fold
+    // (115k against 118k captions/s folded: its projection stays on the side-stream schedule,
+    // and without fc1 in front of it the projection takes the compute units before the
+    // attention arrives).
     const char* fold_env = getenv("ICAP_FOLD_FC");  // tuning knob, read per engine
-    e->fold = !(fold_env && fold_env[0] == '0');
+    e->fold = fold_env ? fold_env[0] != '0' : c.precision == ICAP_PRECISION_FP32;
   }
   e->fin2 = (uint8_t*)(b + o_fin2);
   e->len2 = (int32_t*)(b + o_len2);
   e->flags = (int*)(b + o_flags);
   e->tile_rows_done = (unsigned*)(b + o_trd);
+  e->q_done = (unsigned*)(b + o_qd);
   {
     // opt-in (ICAP_BEAM_IN_LAUNCH=1, read per engine): measured 7 % slower than the separate
     // beam-records kernel at the headline shape

@@ -17,6 +17,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifdef ICAP_TIMELINE
+#define ICAP_ATT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 4096) icap_tl_f32[blockIdx.x][i] = wall_clock64();
+extern __device__ long long icap_tl_f32[4096][8];
+#endif
 #include "attention_body.h"
 #include "beam_records_body.h"
 #include "icap_common.h"
@@ -398,14 +402,19 @@ __device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
       for (int i = 0; i < TM; ++i) {
         const int row0 = m0 + (wm * TM + i) * 32 + 4 * half;
         float* c0 = p.C + (size_t)row0 * p.ldc + col;
+        // (COH: written through to where every XCD sees it, for a reader inside the same launch)
+        auto put = [](float* dst, float v) {
+          if constexpr (COH) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = v;
+        };
         if (interior) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c0[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) put(c0 + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[i][j][r]);
         } else if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) c0[(size_t)dr * p.ldc] = acc[i][j][r];
+            if (row0 + dr < p.M) put(c0 + (size_t)dr * p.ldc, acc[i][j][r]);
           }
         }
       }
@@ -472,16 +481,95 @@ __global__ __launch_bounds__(WM* WN * 64, MINW)
 // the same compute units.  One launch on one stream replaces a second stream, its two
 // event dependencies per step and the separate query kernel.  att_blocks is a multiple of 8
 // so that the tile workgroups keep their XCD.
+#ifdef ICAP_TIMELINE
+// Experiment builds only: start and end of every workgroup of the merged launch on the
+// 100 MHz clock, read back through icap_debug_timeline_f32.
+#define ICAP_STAMP_F32(i) if (threadIdx.x == 0 && blockIdx.x < 4096) icap_tl_f32[blockIdx.x][i] = wall_clock64();
+#else
+#define ICAP_STAMP_F32(i)
+#endif
+
 template <int TOPK, int RB>
 __global__ __launch_bounds__(512, 4)  // (min 4 waves per SIMD: two workgroups per compute unit)
     void dense_topk_attention_kernel(DenseArgs p, AttArgs a, int att_blocks) {
   __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
+  ICAP_STAMP_F32(0)
   if ((int)blockIdx.x < att_blocks) {
     __builtin_amdgcn_s_setprio(3);  // (get out of the tiles' way sooner)
     attention_fq_body<512, RB, (RB <= 3 ? 2 : 1)>(a, reinterpret_cast<char*>(&lds), blockIdx.x, att_blocks);
+    ICAP_STAMP_F32(1)
     return;
   }
   dense_fast_body<128, 128, 4, 2, TOPK>(p, blockIdx.x - att_blocks, lds);
+  ICAP_STAMP_F32(1)
+}
+
+// The same launch with the query projection as matrix tiles of its own instead of a product
+// inside every attention workgroup (where each of them streams the whole [H,U] kernel for its
+// six rows: 65 of an attention workgroup's 122 us at the headline shape).  Grid: nq tiles of
+// 64 x 128 of q = state . W2 + b2 first, then the attention workgroups, then the vocab tiles.
+// The query tiles store q with device scope and count themselves on *q_done; an attention
+// workgroup waits (one lane polling, with a sleep) until the count reaches q_target and
+// reads q with device scope.  Workgroups start in grid order, so the query tiles never wait
+// for a slot held by a waiting attention workgroup; should a wait run out all the same
+// (2^16 polls, a fraction of a second) the workgroup raises *err and leaves its rows
+// untouched - the caller turns that into an invalid result rather than a wrong one.
+template <int TOPK, int RB>
+__global__ __launch_bounds__(512, 4)
+    void dense_topk_attq_kernel(DenseArgs p, DenseArgs pq, AttArgs a, int nq, int att_blocks,
+                                int tiles_before, unsigned* q_done, unsigned q_target, int* err) {
+  __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
+  static_assert(sizeof(typename FastLds<64, 128, 2, 4, 0>::U) <= sizeof(lds), "the query tile's LDS lives in the vocab tile's");
+  // (both leading sections are padded to multiples of 8 workgroups so that the vocab tiles
+  // keep their XCD; the padding workgroups return at once)
+  const int nq_pad = (nq + 7) & ~7, att_pad = (att_blocks + 7) & ~7;
+  // grid order: query tiles, the first tiles_before vocab tiles (a multiple of 8), the
+  // attention workgroups, the other vocab tiles
+  int b = blockIdx.x;
+  int tile_id = -1;
+  if (b >= nq_pad) {
+    if (b < nq_pad + tiles_before) { tile_id = b - nq_pad; }
+    else if (b >= nq_pad + tiles_before + att_pad) { tile_id = b - nq_pad - att_pad; }
+    else { b -= tiles_before; }
+  }
+  ICAP_STAMP_F32(0)
+  if (tile_id >= 0) {
+    dense_fast_body<128, 128, 4, 2, TOPK>(p, tile_id, lds);
+    ICAP_STAMP_F32(1)
+    return;
+  }
+  if (b < nq_pad) {
+    if (b >= nq) return;
+    dense_fast_body<64, 128, 2, 4, 0, true>(pq, b, *reinterpret_cast<typename FastLds<64, 128, 2, 4, 0>::U*>(&lds));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of the tile acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ICAP_STAMP_F32(1)
+    return;
+  }
+  if (b < nq_pad + att_pad) {
+    if (b - nq_pad >= att_blocks) return;
+    int* s_ok = reinterpret_cast<int*>(&lds);
+    if (threadIdx.x == 0) {
+      unsigned polls = 0;
+      bool ok = true;
+      while (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_target) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++polls > (1u << 16)) { ok = false; break; }
+      }
+      if (!ok) *err = 1;
+      *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __syncthreads();  // (the attention body reuses the word's LDS)
+    ICAP_STAMP_F32(2)
+    if (!ok) return;
+    __builtin_amdgcn_s_setprio(3);
+    attention_body<512, RB, 2, true, ATT_ACT_TANH, true>(a, reinterpret_cast<char*>(&lds), b - nq_pad, att_blocks);
+    ICAP_STAMP_F32(1)
+    return;
+  }
 }
 
 // The vocab projection with its top-k epilogue, carrying the beam-search step that consumes
@@ -1645,6 +1733,78 @@ int dense_topk_attention_f32(const float* x, int lda, const float* w, const floa
   return ICAP_OK;
 }
 
+// dense_topk_attention_f32 with the query projection as matrix tiles of the same launch
+// (dense_topk_attq_kernel).  q [G*R, U] is scratch the launch fills; q_done counts finished
+// query tiles over the launches of a decode (the caller zeroes it once and passes the count
+// this launch must reach); err is raised if an attention workgroup's wait runs out.
+bool dense_topk_attq_supported(int R, int L, int U, int D, int H, int top_k) {
+  return dense_topk_attention_supported(R, L, U, D, H, top_k) && U % 128 == 0 && H % 32 == 0 && U <= 512 &&
+         sizeof(float) * attention_lds_floats(512, R, R, L, D) <= 64 * 1024;
+}
+
+int dense_topk_attq_tiles(int rows, int U) { return ceil_div(rows, 64) * (U / 128); }
+
+int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bias, int M, int K,
+                        int N, int eos, int top_k, float* records, float* eos_logit,
+                        const LogitMasks* masks, const float* pf, const float* features,
+                        const float* att_v, float att_bv, const float* state,
+                        const float* gate_w, float gate_b, const float* q_w, const float* q_b,
+                        float* q, float* ctx, int G, int R, int stride_g, int stride_k, int L, int U,
+                        int D, int H, int att_blocks, unsigned* q_done, unsigned q_target, int* err,
+                        hipStream_t s) {
+  ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_attq_f32: null pointer");
+  ICAP_REQUIRE(pf && features && att_v && state && gate_w && q_w && q && ctx && q_done && err,
+               "dense_topk_attq_f32: null attention pointer");
+  ICAP_REQUIRE(lda >= K && lda % 4 == 0 && (long long)M * lda < (1LL << 31),
+               "dense_topk_attq_f32: bad row stride %d", lda);
+  ICAP_REQUIRE(dense_topk_supported(x, w, M, K, N, top_k) && aligned16(records),
+               "dense_topk_attq_f32: projection shape not served (M=%d K=%d N=%d top_k=%d)", M, K, N,
+               top_k);
+  ICAP_REQUIRE(G > 0 && dense_topk_attq_supported(R, L, U, D, H, top_k),
+               "dense_topk_attq_f32: attention shape not served (R=%d L=%d U=%d D=%d H=%d)", R, L, U, D, H);
+  ICAP_REQUIRE(aligned16(pf) && aligned16(features) && aligned16(att_v) && aligned16(q_w) &&
+                   aligned16(ctx) && aligned16(state) && aligned16(q),
+               "dense_topk_attq_f32: attention operands must be 16-byte aligned");
+  DenseArgs a{x, w, bias, nullptr, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, records, eos_logit, eos};
+  if (masks) a.masks = *masks;
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, 128);
+  a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  // q = state . q_w + q_b over all G*R rows, 64 x 128 tiles
+  const int rows = G * R;
+  DenseArgs aq{state, q_w, q_b, q, rows, U, H, H, U, U, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};
+  aq.tiles_m = ceil_div(rows, 64);
+  aq.tiles_n = U / 128;
+  const int nq = aq.tiles_m * aq.tiles_n;
+  att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
+  AttArgs t{pf, features, q, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
+            G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
+  const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + a.tiles_m * a.tiles_n), block(512);
+  // Where the attention workgroups sit in the grid.  In front of every tile they hold one of
+  // each compute unit's two slots from the start and the launch ends on a partly filled round
+  // of tile pairs; behind one full round of tiles plus half of the slots that round frees,
+  // they start beside the second round's tiles and the tiles left for the end are fewer than
+  // the compute units (headline shape: 156 us for any value in 704..736 against 176 us in
+  // front, 169 us behind every tile).  Tuning knob ICAP_ATTQ_TILES_BEFORE.
+  static const char* tb_env = getenv("ICAP_ATTQ_TILES_BEFORE");
+  const int slots = 512, nq_pad = (nq + 7) & ~7;
+  int tiles_before = tb_env ? atoi(tb_env) : slots + (slots - nq_pad) / 2;
+  tiles_before &= ~7;
+  if (tiles_before < 0) tiles_before = 0;
+  if (tiles_before > a.tiles_m * a.tiles_n) tiles_before = (a.tiles_m * a.tiles_n) & ~7;
+#define ICAP_ATTQ(TK, RB_) hipLaunchKernelGGL((dense_topk_attq_kernel<TK, RB_>), grid, block, 0, s, a, aq, t, nq, att_blocks, tiles_before, q_done, q_target, err)
+  switch (R) {
+    case 1: ICAP_ATTQ(1, 1); break;
+    case 2: ICAP_ATTQ(3, 2); break;
+    case 3: ICAP_ATTQ(3, 3); break;
+    case 4: ICAP_ATTQ(5, 4); break;
+    default: ICAP_ATTQ(5, 5); break;
+  }
+#undef ICAP_ATTQ
+  ICAP_LAUNCH_CHECK("dense_topk_attq_kernel");
+  return ICAP_OK;
+}
+
 namespace {
 
 template <int CELL>
@@ -1778,3 +1938,10 @@ int gru_step_f32(const float* ctx, const float* emb, const float* table, const i
 }
 
 }  // namespace icap
+
+#ifdef ICAP_TIMELINE
+__device__ long long icap_tl_f32[4096][8];
+extern "C" int icap_debug_timeline_f32(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(icap_tl_f32), sizeof(long long) * 8 * (n < 4096 ? n : 4096));
+}
+#endif

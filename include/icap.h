@@ -480,8 +480,8 @@ int icap_engine_set_overlap(icap_engine* engine, int on);
  * forms the folded kernel and bias once (icap_engine_create / icap_engine_refresh_weights;
  * sums in double precision, rounded to float32 once) and projects the cell output directly,
  * which removes one launch per decode step; on == 0 keeps the reference's two products
- * (default: folded, or the two products with ICAP_FOLD_FC=0 in the environment when the
- * engine is created).  The logits of the two forms differ by float32 rounding only (both
+ * (default: folded in fp32 mode, the two products in split mode; ICAP_FOLD_FC=0|1 in the
+ * environment when the engine is created overrides).  The logits of the two forms differ by float32 rounding only (both
  * within the 1e-5 bar of the oracle).  ICAP_ERR_UNSUPPORTED in bf16 mode with on != 0. */
 int icap_engine_set_fold_fc(icap_engine* engine, int on);
 /* 1 when the engine carries the next step's query projection and attention in the first

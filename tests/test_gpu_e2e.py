@@ -174,6 +174,27 @@ def test_decode_schedules(monkeypatch, schedule, W):
         assert nbad == 0
 
 
+QTILES = dict(F=48, D=32, E=24, H=128, V=200)      # U = H = 128: the query projection as tiles of the launch
+
+
+@pytest.mark.parametrize("W", [1, 2, 3, 5])
+@pytest.mark.parametrize("qtiles", ["1", "0"])
+def test_decode_merged_launch_with_query_tiles(monkeypatch, W, qtiles):
+    """The merged launch with the next step's query projection as matrix tiles of the same
+    launch (device-scope hand-over of q to the attention workgroups, which wait on a counter)
+    and, for comparison, with the product inside every attention workgroup; 20 images, so the
+    leading sections of the grid are padded."""
+    monkeypatch.setenv("ICAP_MERGED_QTILES", qtiles)
+
+    def setup(eng):
+        assert eng.fused_vocab and eng.merged_launch
+
+    for tile_mode in ("reference", "repeat"):
+        nbad, _ = _compare_decode({}, QTILES, seed=21 + W, B=20, L=6, T=6, W=W, tile_mode=tile_mode,
+                                  bias_seed=5, setup=setup)
+        assert nbad == 0
+
+
 @pytest.mark.parametrize("W,V", [(3, 1000), (5, 10000)])
 def test_beam_step_inside_the_projection_launch_over_several_tile_rows(monkeypatch, W, V):
     """ICAP_BEAM_IN_LAUNCH=1 with images spread over several 128-row tiles (their workgroups
