@@ -40,17 +40,27 @@ lib = _lib.load()
 lib.icap_debug_timeline_f32.argtypes = [C.c_void_p, C.c_int]
 assert lib.icap_debug_timeline_f32(out.ctypes.data_as(C.c_void_p), n) == 0
 t = (out - out[:, 0].min()) / 100.0
-if not nq:
-    print('  attention phases (us since the workgroup started, medians): query done %.1f, image 1 scores done %.1f, image 2 starts %.1f, end %.1f' % tuple(np.median(t[:att, k] - t[:att, 0]) for k in (2, 5, 4, 1)))
+idx = np.arange(n)
 if nq:
-    print("  query tiles: end p50 %.1f max %.1f us; attention workgroups past their wait at p50 %.1f max %.1f us" % (
-        np.median(t[:nq, 1]), t[:nq, 1].max(), np.median(t[nq:nq + att, 2]), t[nq:nq + att, 2].max()))
-t = t[nq:]
+    # grid order of dense_topk_attq_kernel: query tiles, tiles_before vocab tiles, the
+    # attention workgroups, the other vocab tiles
+    tb = int(os.environ.get("ICAP_ATTQ_TILES_BEFORE", 512 + (512 - nq) // 2)) & ~7
+    tb = min(tb, tiles & ~7)
+    is_q = idx < nq
+    is_att = (idx >= nq + tb) & (idx < nq + tb + att)
+    print("  query tiles: end p50 %.1f max %.1f us; attention workgroups past their wait %.1f us (p50) after they start" % (
+        np.median(t[is_q, 1]), t[is_q, 1].max(), np.median(t[is_att, 2] - t[is_att, 0])))
+else:
+    is_q = idx < 0
+    is_att = idx < att
+    print("  attention phases (us since the workgroup started, medians): query done %.1f, image 1 scores done %.1f, "
+          "image 2 starts %.1f, end %.1f" % tuple(np.median(t[is_att, k] - t[is_att, 0]) for k in (2, 5, 4, 1)))
+is_tile = ~is_q & ~is_att
 print("launch span %.1f us; %d attention workgroups, %d tiles" % (t[:, 1].max(), att, tiles))
-for name, sl in (("attention", slice(0, att)), ("tiles", slice(att, n))):
-    s, e = t[sl, 0], t[sl, 1]
-    d = e - s
+for name, sel in (("attention", is_att), ("tiles", is_tile)):
+    s_, e_ = t[sel, 0], t[sel, 1]
+    d = e_ - s_
     q = lambda a: tuple(np.percentile(a, [0, 10, 50, 90, 100]))
-    print("  %-9s start  min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f" % ((name,) + q(s)))
-    print("  %-9s end    min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f" % ((name,) + q(e)))
+    print("  %-9s start  min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f" % ((name,) + q(s_)))
+    print("  %-9s end    min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f" % ((name,) + q(e_)))
     print("  %-9s length min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f" % ((name,) + q(d)))

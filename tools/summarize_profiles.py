@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def classify(name, grid, block):
+    if "dense_topk_attq_kernel" in name or "dense_topk_attention_kernel" in name:
+        return "vocab_projection"   # the merged launch: projection tiles + next step's attention
     if "dense_f32_fast_kernel<128" in name:
         topk = not name.rstrip(")").rstrip("(icap::(anonymous namespace)::DenseArgs").endswith(", 0>")
         return "vocab_projection" if (topk or grid // max(block, 1) == 948) else "dense128_other"
