@@ -91,6 +91,13 @@ int dense_topk_attention_f32(const float*, int, const float*, const float*, int,
                              const float*, float*, int, int, int, int, int, int, int, int, int,
                              hipStream_t);
 bool dense_topk_attq_supported(int R, int L, int U, int D, int H, int top_k);
+bool dense_topk_bf16_attq_supported(int R, int L, int U, int D, int H, int top_k);
+int dense_topk_bf16_attq_tiles(int rows, int U);
+int dense_topk_bf16_attq(const void*, const void*, const float*, int, int, int, int, int, float*, float*,
+                         const LogitMasks*, const float*, const float*, const float*, float,
+                         const float*, const float*, float, const void*, const float*, float*, float*,
+                         int, int, int, int, int, int, int, int, int, unsigned*, unsigned, int*,
+                         hipStream_t);
 int dense_topk_attq_tiles(int rows, int U);
 int dense_topk_attq_f32(const float*, int, const float*, const float*, int, int, int, int, int,
                         float*, float*, const LogitMasks*, const float*, const float*,
@@ -483,8 +490,11 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // seen to hang on their event waits)
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capture);
+  const bool bf16 = c.precision == ICAP_PRECISION_BF16;
+  // (bf16 mode: the merged launch takes the row-major bf16 activations fc1 hands over)
   const bool merged = e->merged && e->overlap && topk != 0 && !wide &&
-                      capture == hipStreamCaptureStatusNone;
+                      capture == hipStreamCaptureStatusNone &&
+                      (!bf16 || (e->a16 && !dense_topk_bf16_a16_blocked(N, c.H, c.V, topk)));
   const bool side = e->overlap && !merged;
   const int att_blocks = e->side_att_wgs > 0 ? e->side_att_wgs : c.B;
   // the output projection's operands: the folded kernel applied to the LSTM output, or fc2
@@ -494,9 +504,17 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   const float* vb = fold ? e->b12 : w.fc2_bias;
   const void* vpk = fold ? e->pk_fold : e->pk[icap_engine::PK_FC2];
   unsigned q_launches = 0;
-  const int nq_tiles = dense_topk_attq_tiles((int)N, c.U);
+  const int nq_tiles = bf16 ? dense_topk_bf16_attq_tiles((int)N, c.U) : dense_topk_attq_tiles((int)N, c.U);
   auto vocab_with_attention = [&](const float* x, int lda, int rows, const LogitMasks* mk,
                                   const float* state) -> int {
+    if (bf16)  // (x: fc1's fp32 output, unused - the projection reads its bf16 copy)
+      return dense_topk_bf16_attq(e->fc1o16, e->pk[icap_engine::PK_FC2], w.fc2_bias, rows, c.H, c.V,
+                                  c.eos_id, topk, e->rec, e->eos_x, mk, e->pf, features,
+                                  w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
+                                  e->pk[icap_engine::PK_W2], w.att_w2_bias, e->q, e->ctx, c.B, c.W,
+                                  stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
+                                  ++q_launches * (unsigned)nq_tiles,
+                                  reinterpret_cast<int*>(e->q_done + 1), s);
     if (e->qtiles)
       return dense_topk_attq_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk,
                                  e->pf, features, w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel,
@@ -641,7 +659,9 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       }
       {
         Timed tm(e, ICAP_K_VOCAB, s);
-        if (a16)
+        if (bf16 && merged && t + 1 < c.T)
+          ICAP_TRY(vocab_with_attention(vx, c.H, N, mk, gru ? e->h[cur] : e->c));
+        else if (a16)
           ICAP_TRY(dense_topk_bf16_a16(e->fc1o16, a16_blocked, e->pk[icap_engine::PK_FC2], w.fc2_bias,
                                        N, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk, s));
         else if (c.precision == ICAP_PRECISION_BF16)
@@ -1120,6 +1140,16 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const char* qt_env = getenv("ICAP_MERGED_QTILES");
     e->qtiles = e->merged && !(qt_env && qt_env[0] == '0') &&
                 dense_topk_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able);
+    // bf16 mode: the same arrangement around the bf16 record projection (query tiles always),
+    // on request only (ICAP_MERGED=1): 152-165k against 176k captions/s on the side stream at
+    // beam 5 - the record epilogue of these tiles and the attention both load the vector unit,
+    // and with fc1 in front of the projection the side-stream attention is resident first
+    if (c.precision == ICAP_PRECISION_BF16) {
+      e->merged = merged_env && merged_env[0] == '1' && e->topk_able != 0 && c.W <= 5 &&
+                  dense_topk_bf16_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able) &&
+                  aligned16(weights->att_v_kernel);
+      e->qtiles = e->merged;
+    }
   }
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lstm, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_att, hipEventDisableTiming);

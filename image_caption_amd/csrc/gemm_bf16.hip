@@ -18,13 +18,14 @@
 
 #include "icap_common.h"
 #include "topk_epilogue.h"
+#include "attention_body.h"
 
 #ifdef ICAP_TIMELINE
 // Experiment builds only (-DICAP_TIMELINE): every workgroup of gemm_bf16_kernel leaves the
 // 100 MHz clock at four points of its life, read back through icap_debug_timeline.
 __device__ long long g_timeline[8192][4];
 // ICAP_TIMELINE = 2 stamps only the launches with the top-k record epilogue (inside a decode)
-#define ICAP_STAMP(i) if ((ICAP_TIMELINE != 2 || TOPK > 0) && threadIdx.x == 0 && blockIdx.x < 8192) g_timeline[blockIdx.x][i] = wall_clock64();
+#define ICAP_STAMP(i) if ((ICAP_TIMELINE != 2 || TOPK > 0) && threadIdx.x == 0 && bid < 8192) g_timeline[bid][i] = wall_clock64();
 extern "C" int icap_debug_timeline(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(long long) * 4 * (n < 8192 ? n : 8192));
 }
@@ -85,8 +86,19 @@ struct Bf16Args {
 // same round-to-nearest-even as the staging conversion, so the products are the same): half
 // the operand traffic, and at the vocab projection's shape the 2.6 MB activation panel then
 // stays in an XCD's L2 beside its band of weight panels.
-template <int BM, bool LSTM, int TOPK = 0, bool A16 = false>
-__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Args p) {
+// LDS bytes of a tile workgroup: two operand stages, reused by the epilogues
+template <int BM, bool LSTM, int TOPK>
+constexpr int gemm_bf16_smem_bytes() {
+  constexpr int stages = 2 * (BM * ROW_B + BN * ROW_B);
+  constexpr int z = LSTM ? BM * ZLD * 4 : (TOPK > 0 ? 4 * (BM / 2) * 68 * 4 : 0);
+  return stages > z ? stages : z;
+}
+
+// One tile by a 256-thread workgroup; bid = position in the tile grid, smem = the workgroup's
+// LDS (gemm_bf16_smem_bytes).  COH: the plain epilogue stores y with device scope, for a
+// reader inside the same launch (the query tiles of vocab_bf16_attq_kernel).
+template <int BM, bool LSTM, int TOPK = 0, bool A16 = false, bool COH = false>
+__device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid, char* const smem) {
   constexpr int NT = 256;
   constexpr int WTM = BM / 2;    // wave tile rows
   constexpr int TM = WTM / 32;   // accumulators along m
@@ -97,10 +109,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
   constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int T_LD = 68;  // floats per row of a wave's transposition patch (top-k epilogue)
-  constexpr int Z_BYTES = LSTM ? BM * ZLD * 4 : (TOPK > 0 ? 4 * WTM * T_LD * 4 : 0);
   static_assert(TOPK == 0 || (!LSTM && BM == 128), "the top-k epilogue is built for 128-row tiles");
-  constexpr int SMEM = 2 * STAGE > Z_BYTES ? 2 * STAGE : Z_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   ICAP_STAMP(0)
   if constexpr (TOPK > 0) {
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
     // both phases in lockstep and use one resource at a time.  Delaying one of them once puts
     // the K loop of one beside the epilogue of the other; the offset carries over to the
     // later rounds, whose workgroups start when their predecessors end.
-    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_wgs) {
+    if (p.stagger_ticks > 0 && bid < p.stagger_wgs) {
       // (the word lives in the staging buffer: a second LDS object would make the compiler
       // drain the memory queue in front of every K stage's LDS reads)
       volatile unsigned* s_arrival = reinterpret_cast<volatile unsigned*>(smem);
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
     }
   }
   int tile_m, tile_n;
-  tile_of_block_band(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  tile_of_block_band(bid, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -291,8 +300,11 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
     const int row = m0 + wm * WTM + lane;
-    if (p.masks.any()) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
-    const TopkRow<TOPK> rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
+    const bool masked = p.masks.any();
+    if (masked) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
+    TopkRow<TOPK> rec;
+    if constexpr (TOPK > 1) rec = topk_scan_keyed<TOPK, 64>(x, patch + lane * T_LD, colbase, p.eos, masked);
+    else rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
     if (row < p.M) {
       if (rec.has_eos) p.eos_x[row] = rec.eos_v;
       topk_store<TOPK>(p.rec + ((size_t)row * (2 * p.tiles_n) + 2 * tile_n + wn) * RL, rec);
@@ -311,7 +323,8 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
           float v = acc[i][j][r] + bv;
           if (p.act == ICAP_ACT_RELU) v = fmaxf(v, 0.f);
           if (n_ok && m < p.M) {
-            p.y[(size_t)m * p.N + n] = v;
+            if constexpr (COH) __hip_atomic_store(p.y + (size_t)m * p.N + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else p.y[(size_t)m * p.N + n] = v;
             if (p.y16) {
               // blocked: [m/32][n/16][(n%16)/8][m%32][n%8] - a wave's MFMA A operand for a k-step
               // of 16 is then one contiguous kilobyte
@@ -368,6 +381,74 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Ar
     }
   }
   ICAP_STAMP(3)
+}
+
+template <int BM, bool LSTM, int TOPK = 0, bool A16 = false>
+__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[gemm_bf16_smem_bytes<BM, LSTM, TOPK>()];
+  gemm_bf16_body<BM, LSTM, TOPK, A16>(p, blockIdx.x, smem);
+}
+
+// The record projection on bf16 activations carrying the NEXT decode step's query projection
+// and attention in the same launch (the bf16 counterpart of dense_topk_attq_kernel): that
+// attention depends only on the recurrent state the cell kernel has written, not on this
+// projection.  One launch on one stream replaces the side stream, its event dependencies (a
+// wait and a record on the main stream per step, several microseconds each) and the query
+// kernel.  Grid order: nq tiles of 64 x 128 of q = state . W2 + b2 (padded to a multiple of
+// 8 workgroups, as is the attention section, so that the vocab tiles keep their XCD), the
+// first tiles_before vocab tiles, the attention workgroups, the other vocab tiles.  The
+// query tiles store q with device scope and count themselves on *q_done; an attention
+// workgroup waits (one lane polling, with a sleep) until the count reaches q_target and
+// reads q with device scope.  Workgroups start in grid order, so the query tiles never wait
+// for a slot held by a waiting attention workgroup; should a wait run out all the same
+// (2^16 polls, a fraction of a second) the workgroup raises *err and leaves its rows
+// untouched - the caller turns that into an invalid result rather than a wrong one.
+template <int TOPK, int RB>
+__global__ __launch_bounds__(256, 2) void vocab_bf16_attq_kernel(Bf16Args p, Bf16Args pq, AttArgs a,
+                                                                 int nq, int att_blocks,
+                                                                 int tiles_before, unsigned* q_done,
+                                                                 unsigned q_target, int* err) {
+  __shared__ __attribute__((aligned(16))) char smem[gemm_bf16_smem_bytes<128, false, TOPK>()];
+  static_assert(gemm_bf16_smem_bytes<64, false, 0>() <= gemm_bf16_smem_bytes<128, false, TOPK>(),
+                "the query tile's LDS lives in the vocab tile's");
+  const int nq_pad = (nq + 7) & ~7, att_pad = (att_blocks + 7) & ~7;
+  int b = blockIdx.x;
+  int tile_id = -1;
+  if (b >= nq_pad) {
+    if (b < nq_pad + tiles_before) { tile_id = b - nq_pad; }
+    else if (b >= nq_pad + tiles_before + att_pad) { tile_id = b - nq_pad - att_pad; }
+    else { b -= tiles_before; }
+  }
+  if (tile_id >= 0) {
+    gemm_bf16_body<128, false, TOPK, true>(p, tile_id, smem);
+    return;
+  }
+  if (b < nq_pad) {
+    if (b >= nq) return;
+    gemm_bf16_body<64, false, 0, false, true>(pq, b, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of the tile acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(q_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (b - nq_pad >= att_blocks) return;
+  int* s_ok = reinterpret_cast<int*>(smem);
+  if (threadIdx.x == 0) {
+    unsigned polls = 0;
+    bool ok = true;
+    while (__hip_atomic_load(q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_target) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++polls > (1u << 16)) { ok = false; break; }
+    }
+    if (!ok) *err = 1;
+    *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  const bool ok = *s_ok != 0;
+  __syncthreads();  // (the attention body reuses the word's LDS)
+  if (!ok) return;
+  __builtin_amdgcn_s_setprio(3);
+  attention_body<256, RB, 2, true, ATT_ACT_TANH, true>(a, smem, b - nq_pad, att_blocks);
 }
 
 // w[K_src][N] fp32 -> packed[n'][k_off + k] bf16, n' = n or the gate-interleaved column.
@@ -548,6 +629,83 @@ int dense_topk_bf16_a16(const void* x16, int blocked, const void* packed_w, cons
   else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5, true>), grid, block, 0, s, a);
   ICAP_LAUNCH_CHECK("gemm_bf16_kernel<topk,a16>");
+  return ICAP_OK;
+}
+
+// dense_topk_bf16_a16 (row-major x16) with the next step's query projection and attention in
+// the same launch (vocab_bf16_attq_kernel).  q [G*R, U] is scratch the launch fills; q_done
+// counts finished query tiles over the launches of a decode (the caller zeroes it once and
+// passes the count this launch must reach); err is raised if an attention workgroup's wait
+// runs out.
+bool dense_topk_bf16_attq_supported(int R, int L, int U, int D, int H, int top_k) {
+  if (R < 1 || R > 5 || L < 1 || U < 4 || U > 512 || U % 4 || D < 4 || D % 4 || H < BK || H % BK)
+    return false;
+  if (top_k != (R <= 1 ? 1 : (R <= 3 ? 3 : 5))) return false;
+  return sizeof(float) * attention_lds_floats(256, R, R, L, D) <= 64 * 1024;
+}
+
+int dense_topk_bf16_attq_tiles(int rows, int U) { return ceil_div(rows, 64) * ceil_div(U, BN); }
+
+int dense_topk_bf16_attq(const void* x16, const void* packed_w, const float* bias, int M, int K, int N,
+                         int eos, int top_k, float* records, float* eos_logit,
+                         const LogitMasks* masks, const float* pf, const float* features,
+                         const float* att_v, float att_bv, const float* state, const float* gate_w,
+                         float gate_b, const void* packed_q_w, const float* q_b, float* q, float* ctx,
+                         int G, int R, int stride_g, int stride_k, int L, int U, int D, int H,
+                         int att_blocks, unsigned* q_done, unsigned q_target, int* err,
+                         hipStream_t s) {
+  ICAP_REQUIRE(x16 && packed_w && records && eos_logit, "dense_topk_bf16_attq: null pointer");
+  ICAP_REQUIRE(pf && features && att_v && state && gate_w && packed_q_w && q && ctx && q_done && err,
+               "dense_topk_bf16_attq: null attention pointer");
+  ICAP_REQUIRE((top_k == 1 || top_k == 3 || top_k == 5) && M > 0 && N > 0 && K > 0 && K % BK == 0,
+               "dense_topk_bf16_attq: needs top_k in {1,3,5} and K %% 64 == 0 (M=%d K=%d N=%d top_k=%d)",
+               M, K, N, top_k);
+  ICAP_REQUIRE(G > 0 && dense_topk_bf16_attq_supported(R, L, U, D, H, top_k),
+               "dense_topk_bf16_attq: attention shape not served (R=%d L=%d U=%d D=%d H=%d)", R, L, U, D, H);
+  ICAP_REQUIRE(aligned16(x16) && aligned16(packed_w) && aligned16(records) && aligned16(pf) &&
+                   aligned16(features) && aligned16(att_v) && aligned16(packed_q_w) && aligned16(ctx) &&
+                   aligned16(state) && aligned16(q),
+               "dense_topk_bf16_attq: operands must be 16-byte aligned");
+  Bf16Args a = {};
+  a.a16 = static_cast<const uint16_t*>(x16); a.lda16 = K; a.K0 = K;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = bias; a.y = nullptr; a.M = M; a.N = N; a.K = K; a.act = ICAP_ACT_NONE;
+  a.rec = records; a.eos_x = eos_logit; a.eos = eos;
+  if (masks) a.masks = *masks;
+  a.tiles_m = ceil_div(M, 128);
+  a.tiles_n = ceil_div(N, BN);
+  // q = state . q_w + q_b over all G*R rows, 64 x 128 tiles
+  const int rows = G * R;
+  Bf16Args aq = {};
+  aq.a0 = state; aq.a1 = nullptr; aq.K0 = H; aq.lda0 = H; aq.lda1 = 0;
+  aq.w = static_cast<const uint16_t*>(packed_q_w);
+  aq.bias = q_b; aq.y = q; aq.M = rows; aq.N = U; aq.K = H; aq.act = ICAP_ACT_NONE;
+  aq.tiles_m = ceil_div(rows, 64);
+  aq.tiles_n = ceil_div(U, BN);
+  const int nq = aq.tiles_m * aq.tiles_n;
+  att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
+  AttArgs t{pf, features, q, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
+            G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
+  const int tiles = a.tiles_m * a.tiles_n;
+  const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + tiles), block(256);
+  // Where the attention workgroups sit in the grid (tuning knob ICAP_BF16_ATTQ_TILES_BEFORE):
+  // behind one round of resident tiles (two per compute unit) less the query tiles.
+  static const char* tb_env = getenv("ICAP_BF16_ATTQ_TILES_BEFORE");
+  const int slots = 512, nq_pad = (nq + 7) & ~7;
+  int tiles_before = tb_env ? atoi(tb_env) : slots - nq_pad;
+  tiles_before &= ~7;
+  if (tiles_before < 0) tiles_before = 0;
+  if (tiles_before > tiles) tiles_before = tiles & ~7;
+#define ICAP_ATTQ16(TK, RB_) hipLaunchKernelGGL((vocab_bf16_attq_kernel<TK, RB_>), grid, block, 0, s, a, aq, t, nq, att_blocks, tiles_before, q_done, q_target, err)
+  switch (R) {
+    case 1: ICAP_ATTQ16(1, 1); break;
+    case 2: ICAP_ATTQ16(3, 2); break;
+    case 3: ICAP_ATTQ16(3, 3); break;
+    case 4: ICAP_ATTQ16(5, 4); break;
+    default: ICAP_ATTQ16(5, 5); break;
+  }
+#undef ICAP_ATTQ16
+  ICAP_LAUNCH_CHECK("vocab_bf16_attq_kernel");
   return ICAP_OK;
 }
 

@@ -452,8 +452,11 @@ __device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
       const float4 v = *reinterpret_cast<const float4*>(patch + lr * T_LD + part * 32 + 4 * q);
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
-    if (p.masks.any()) apply_logit_masks<32>(x, cbase, row, p.M, p.masks);
-    TopkRow<TOPK> rec = topk_scan<TOPK, 32>(x, cbase, p.eos);
+    const bool masked = p.masks.any();
+    if (masked) apply_logit_masks<32>(x, cbase, row, p.M, p.masks);
+    TopkRow<TOPK> rec;
+    if constexpr (TOPK > 1) rec = topk_scan_keyed<TOPK, 32>(x, patch + lr * T_LD + part * 32, cbase, p.eos, masked);
+    else rec = topk_scan<TOPK, 32>(x, cbase, p.eos);
     if (rec.has_eos && row < p.M) {
       if constexpr (COH) __hip_atomic_store(p.eos_x + row, rec.eos_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else p.eos_x[row] = rec.eos_v;

@@ -234,8 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitArgs p) {
       x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
     const int row = m0 + wm * WTM + lane;
-    if (p.masks.any()) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
-    const TopkRow<TOPK> rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
+    const bool masked = p.masks.any();
+    if (masked) apply_logit_masks<64>(x, colbase, row, p.M, p.masks);
+    TopkRow<TOPK> rec;
+    if constexpr (TOPK > 1) rec = topk_scan_keyed<TOPK, 64>(x, patch + lane * T_LD, colbase, p.eos, masked);
+    else rec = topk_scan<TOPK, 64>(x, colbase, p.eos);
     if (row < p.M) {
       if (rec.has_eos) p.eos_x[row] = rec.eos_v;
       topk_store<TOPK>(p.rec + ((size_t)row * (2 * p.tiles_n) + 2 * tile_n + wn) * RL, rec);

@@ -107,6 +107,68 @@ __device__ __forceinline__ TopkRow<TOPK> topk_scan(const float (&x)[NX], int cba
   return r;
 }
 
+// topk_scan for lanes whose NX <= 64 logits also lie in memory (`exact`: LDS, exact[e] == x[e]):
+// the same record with less vector-unit work.  The TOPK + 1 largest are tracked on 32-bit keys -
+// the logit with its low six mantissa bits replaced by the element index - so one
+// v_med3_f32 per level replaces the compare and the two selects per level for the columns.
+// Key order equals logit order wherever the logits differ above those six bits; if two
+// neighbouring keys of the final list agree there (or one of them stands for an infinite or
+// absent logit), the wave repeats the scan with topk_scan, so the record is the exact one in
+// every case.  The values are then read back by element index.  x_differs (uniform over
+// the wave): x[] no longer equals exact[] (masks were applied), take topk_scan at once.
+template <int TOPK, int NX>
+__device__ __forceinline__ TopkRow<TOPK> topk_scan_keyed(const float (&x)[NX], const float* exact,
+                                                          int cbase, int eos, bool x_differs = false) {
+  static_assert(NX <= 64 && NX > TOPK, "six bits of element index, more elements than list entries");
+  constexpr float FMAX = 3.4028234663852886e38f;
+  float t[TOPK + 1];
+#pragma unroll
+  for (int k = 0; k <= TOPK; ++k) t[k] = -INFINITY;
+  const float top = INFINITY;
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    // (clamped: an infinite logit with index bits would be a NaN)
+    const float c = __builtin_amdgcn_fmed3f(x[e], -FMAX, FMAX);
+    const float kf = __uint_as_float((__float_as_uint(c) & 0xffffffc0u) | (unsigned)e);
+#pragma unroll
+    for (int k = TOPK; k >= 1; --k) t[k] = __builtin_amdgcn_fmed3f(t[k - 1], t[k], kf);
+    t[0] = __builtin_amdgcn_fmed3f(t[0], kf, top);  // max, as a median with +inf
+  }
+  bool redo = x_differs;
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k)
+    redo |= ((__float_as_uint(t[k]) ^ __float_as_uint(t[k + 1])) < 64u);
+  // (a clamped or absent logit: the exponent field of its key is all ones but for the lowest bit)
+#pragma unroll
+  for (int k = 0; k <= TOPK; ++k) redo |= ((__float_as_uint(t[k]) & 0x7f000000u) == 0x7f000000u);
+  if (__builtin_amdgcn_ballot_w64(redo) != 0ull) return topk_scan<TOPK, NX>(x, cbase, eos);
+  TopkRow<TOPK> r;
+  r.eos_v = 0.f;
+  r.has_eos = false;
+  {
+    const int e_eos = eos - cbase;
+    const bool hit = (unsigned)e_eos < (unsigned)NX;
+    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+      r.eos_v = exact[hit ? e_eos : 0];
+      r.has_eos = hit;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k) {
+    const int e = (int)(__float_as_uint(t[k]) & 63u);
+    r.tx[k] = exact[e];
+    r.tc[k] = cbase + e;
+  }
+  r.m = r.tx[0];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < NX; e += 4)
+    sum += (fast_exp(x[e] - r.m) + fast_exp(x[e + 1] - r.m)) +
+           (fast_exp(x[e + 2] - r.m) + fast_exp(x[e + 3] - r.m));
+  r.sum = sum;
+  return r;
+}
+
 // Merges the record of the neighbouring lane (lane ^ 1, which holds the HIGHER columns when
 // this lane is even) into this one; meaningful on even lanes.
 template <int TOPK>

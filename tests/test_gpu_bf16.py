@@ -80,7 +80,7 @@ def test_lstm_step_bf16(ops, N, C, H, V, with_emb):
     assert_close(np_of(c_g), c_r, rtol=2e-2, what="c vs fp32")
 
 
-def _decode_pair(B, W, T, dims, seed, precision):
+def _decode_pair(B, W, T, dims, seed, precision, want_merged=None):
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
     L, F, D, E, H, V = dims
     p = co.perturb_biases(co.make_params(seed, F, D, E, H, V), seed + 1)
@@ -90,6 +90,8 @@ def _decode_pair(B, W, T, dims, seed, precision):
                         precision=precision)
     eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
     prefer_fused(eng)
+    if want_merged is not None:
+        assert eng.merged_launch == want_merged
     tokens, best = eng.decode(to_dev(img))
     tr = eng.trace()
     return p, img, np_of(tokens), np_of(best), {k: np_of(v) for k, v in tr.items()}
@@ -192,3 +194,20 @@ def test_engine_bf16_resident_panel_kernel_agrees_with_staged_tiles(monkeypatch)
     np.testing.assert_array_equal(tr0["ids"], tr1["ids"])
     np.testing.assert_array_equal(tr0["parents"], tr1["parents"])
     np.testing.assert_allclose(b0, b1, rtol=3e-6)
+
+
+@pytest.mark.parametrize("W", [1, 3, 5])
+def test_engine_bf16_merged_launch_agrees_with_side_stream(monkeypatch, W):
+    """The opt-in launch that carries the next step's query tiles and attention inside the
+    bf16 record projection (ICAP_MERGED=1 in bf16 mode) runs the same kernels' arithmetic as
+    the side-stream schedule: same tokens, trace and scores."""
+    dims = (16, 128, 64, 64, 256, 3000)
+    monkeypatch.setenv("ICAP_FUSED_TOPK", "1")
+    monkeypatch.setenv("ICAP_MERGED", "0")
+    _, _, t0, b0, tr0 = _decode_pair(40, W, 8, dims, 7, "bf16", want_merged=False)
+    monkeypatch.setenv("ICAP_MERGED", "1")
+    _, _, t1, b1, tr1 = _decode_pair(40, W, 8, dims, 7, "bf16", want_merged=True)
+    np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_array_equal(tr0["ids"], tr1["ids"])
+    np.testing.assert_array_equal(tr0["parents"], tr1["parents"])
+    np.testing.assert_array_equal(b0, b1)
