@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
   ZsT Zs = reinterpret_cast<ZsT>(smem);
   int* row_src = reinterpret_cast<int*>(smem + A_BYTES + B_BYTES);
 
+  ICAP_STAMP_F32(0)
   int tile_m, tile_j;
   tile_of_block(blockIdx.x, p.tiles_m, p.tiles_j, tile_m, tile_j);
   const int m0 = tile_m * BM;
@@ -1258,9 +1259,16 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
   // One barrier per K step, below the next step's loads (see dense_f32_fast_kernel): the
   // prefetch stays in flight during the multiplies, which matters here because there is no
   // second workgroup on the compute unit to cover a memory latency.
+  // (Device-clock stamps at the headline shape, kernel alone: prologue 3.1 us, K loop 42.3 us,
+  // cell update 1.0 us.  Timing experiments on the loop: the multiplies alone 36.2 us (a bare
+  // loop of the same multiplies reaches 0.98 of the matrix peak in a long launch), with the
+  // LDS reads 37.0, with the barrier 36.2; the global loads or the LDS stores, either or
+  // both, add 5 us whether the stores sit behind the multiplies, among them (with the
+  // registers one tile ahead) or in front; two accumulator chains per wave change nothing.)
   const int nk = K / LBK;
   ICAP_LW_LOAD(0)
   ICAP_LW_STORE(0)
+  ICAP_STAMP_F32(2)
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     ICAP_LW_LOAD(min(t + 1, nk - 1) * LBK)  // the last step re-loads its own tile: no branch
@@ -1283,6 +1291,7 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
     ICAP_LW_STORE(buf ^ 1)
   }
   __syncthreads();  // the gate exchange reuses the staging buffers
+  ICAP_STAMP_F32(3)
 #undef ICAP_LW_LOAD
 #undef ICAP_LW_STORE
 
@@ -1303,6 +1312,7 @@ __global__ __launch_bounds__(LW_NT, 1) __attribute__((amdgpu_waves_per_eu(3, 3))
       cell_update_pre<CELL>(p, (size_t)gm * p.H + j0 + u, Zs[0][row][u], Zs[1][row][u], Zs[2][row][u],
                             Zs[3][row][u], st_pre[q]);
   }
+  ICAP_STAMP_F32(1)
 }
 
 // ---------------------------------------------------------------------------------
