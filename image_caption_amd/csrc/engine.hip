@@ -1140,6 +1140,15 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const char* qt_env = getenv("ICAP_MERGED_QTILES");
     e->qtiles = e->merged && !(qt_env && qt_env[0] == '0') &&
                 dense_topk_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able);
+    // With the merged launch the fused path wins from about a hundred beam rows upwards (beam 3:
+    // B = 32 25.2k against 20.6k captions/s, B = 64 45k against 37k, B = 256 83k against 77k;
+    // greedy: B = 128 103k against 88k, B = 1024 244k against 215k; B*W <= 64 stays 4-8 %
+    // faster on the plain projection + unfused step), not only from three tiles per compute
+    // unit as on the side-stream schedule.
+    {
+      static const char* fused_env2 = getenv("ICAP_FUSED_TOPK");
+      if (!fused_env2 && e->merged && N > 64) e->topk = e->topk_able;
+    }
     // bf16 mode: the same arrangement around the bf16 record projection (query tiles always),
     // on request only (ICAP_MERGED=1): 152-165k against 176k captions/s on the side stream at
     // beam 5 - the record epilogue of these tiles and the attention both load the vector unit,
