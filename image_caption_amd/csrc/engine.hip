@@ -1144,10 +1144,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     // B = 32 25.2k against 20.6k captions/s, B = 64 45k against 37k, B = 256 83k against 77k;
     // greedy: B = 128 103k against 88k, B = 1024 244k against 215k; B*W <= 64 stays 4-8 %
     // faster on the plain projection + unfused step), not only from three tiles per compute
-    // unit as on the side-stream schedule.
+    // unit as on the side-stream schedule.  The bf16 and split modes, on the side stream, gain
+    // from the same size on (bf16 beam 3: B = 128 90k against 83k, B = 256 151k against 127k,
+    // greedy B = 1024 478k against 379k; split beam 3: B = 128 64k against 55k, B = 384 101k
+    // against 89k; equal within 1 % at 80-128 rows, the unfused step ahead below).
     {
       static const char* fused_env2 = getenv("ICAP_FUSED_TOPK");
-      if (!fused_env2 && e->merged && N > 64) e->topk = e->topk_able;
+      if (!fused_env2 && N > 64 && !e->wide && (e->merged || c.precision != ICAP_PRECISION_FP32))
+        e->topk = e->topk_able;
     }
     // bf16 mode: the same arrangement around the bf16 record projection (query tiles always),
     // on request only (ICAP_MERGED=1): 152-165k against 176k captions/s on the side stream at

@@ -517,8 +517,8 @@ def test_decode_full_size_is_permutation_equivariant():
 
 
 def test_fused_path_is_the_default_from_one_tile_per_cu_upwards():
-    """Small batches (up to 64 beam rows where the exact-f32 merged launch serves the shape,
-    fewer than about three 128x128 projection tiles per compute unit elsewhere) default to the
+    """Small batches (up to 64 beam rows; wide beams and the exact-f32 side-stream schedule:
+    fewer than about three 128x128 projection tiles per compute unit) default to the
     short-K projection + unfused beam step, larger ones to the fused path; both can be
     selected explicitly and give the same records (test_fused_and_unfused_vocab_paths_agree)."""
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
@@ -529,8 +529,8 @@ def test_fused_path_is_the_default_from_one_tile_per_cu_upwards():
     small.set_fused_vocab(True)
     assert small.fused_vocab
     small.close()
-    for B, W, precision, fused in ((512, 3, "fp32", True), (32, 3, "fp32", True), (32, 3, "bf16", False),
-                                  (64, 1, "fp32", False)):
+    for B, W, precision, fused in ((512, 3, "fp32", True), (32, 3, "fp32", True), (32, 3, "bf16", True),
+                                  (16, 3, "bf16", False), (64, 1, "fp32", False)):
         eng = CaptionEngine(CaptionConfig(B=B, W=W, L=64, F=PROD["F"], D=PROD["D"], E=PROD["E"],
                                           H=PROD["H"], U=PROD["H"], V=PROD["V"], T=2,
                                           precision=precision), p, device=dev())
