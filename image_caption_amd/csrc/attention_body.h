@@ -379,11 +379,7 @@ __device__ __forceinline__ void attention_fq_body(const AttArgs& p, char* smem, 
       const int kgi = tid / quads, quad = tid - kgi * quads;
       const bool active = kgi < KG;
       const int hk = (((p.H + KG - 1) / KG) + 7) & ~7;  // k values per slice
-#ifdef ICAP_EXPERIMENT_SKIP_QUERY  // (timing experiment only: the query product is not computed)
-      const int k_lo = 0, k_hi = 0;
-#else
       const int k_lo = active ? min(kgi * hk, p.H) : 0, k_hi = active ? min(k_lo + hk, p.H) : 0;
-#endif
       float4 acc[ROWS];
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
