@@ -492,7 +492,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   (void)hipStreamIsCapturing(s, &capture);
   const bool bf16 = c.precision == ICAP_PRECISION_BF16;
   // (bf16 mode: the merged launch takes the row-major bf16 activations fc1 hands over)
-  const bool merged = e->merged && e->overlap && topk != 0 && !wide &&
+  const bool merged = e->merged && e->overlap && topk != 0 &&
                       capture == hipStreamCaptureStatusNone &&
                       (!bf16 || (e->a16 && !dense_topk_bf16_a16_blocked(N, c.H, c.V, topk)));
   const bool side = e->overlap && !merged;
@@ -1131,15 +1131,16 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     const char* fold_env0 = getenv("ICAP_FOLD_FC");
     const bool fold_on = fold_able && (fold_env0 ? fold_env0[0] != '0' : c.precision == ICAP_PRECISION_FP32);
     const bool want = merged_env ? merged_env[0] == '1' : fold_on;
-    e->merged = want && c.precision == ICAP_PRECISION_FP32 &&
-                e->topk_able != 0 &&
-                dense_topk_attention_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able) &&
-                aligned16(weights->att_v_kernel) && aligned16(weights->att_w2_kernel);
+    const bool base_ok = want && c.precision == ICAP_PRECISION_FP32 && e->topk_able != 0 &&
+                         aligned16(weights->att_v_kernel) && aligned16(weights->att_w2_kernel);
     // the query projection as tiles of the same launch (ICAP_MERGED_QTILES=0: inside every
-    // attention workgroup instead)
+    // attention workgroup instead, beams up to 5); wide beams take the tiles form only
     const char* qt_env = getenv("ICAP_MERGED_QTILES");
-    e->qtiles = e->merged && !(qt_env && qt_env[0] == '0') &&
+    e->qtiles = base_ok && !(qt_env && qt_env[0] == '0') &&
                 dense_topk_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able);
+    e->merged = e->qtiles ||
+                (base_ok && !e->wide &&
+                 dense_topk_attention_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able));
     // With the merged launch the fused path wins from about a hundred beam rows upwards (beam 3:
     // B = 32 25.2k against 20.6k captions/s, B = 64 45k against 37k, B = 256 83k against 77k;
     // greedy: B = 128 103k against 88k, B = 1024 244k against 215k; B*W <= 64 stays 4-8 %
@@ -1406,7 +1407,7 @@ int icap_engine_set_overlap(icap_engine* e, int on) {
 }
 
 int icap_engine_merged_launch(const icap_engine* e) {
-  return e && e->merged && e->overlap && e->topk != 0 && !e->wide ? 1 : 0;
+  return e && e->merged && e->overlap && e->topk != 0 ? 1 : 0;
 }
 
 int icap_engine_set_fold_fc(icap_engine* e, int on) {

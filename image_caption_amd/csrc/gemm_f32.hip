@@ -1750,9 +1750,26 @@ int dense_topk_attention_f32(const float* x, int lda, const float* w, const floa
 // (dense_topk_attq_kernel).  q [G*R, U] is scratch the launch fills; q_done counts finished
 // query tiles over the launches of a decode (the caller zeroes it once and passes the count
 // this launch must reach); err is raised if an attention workgroup's wait runs out.
+// rows of a group held in registers per pass over PF (as attention_f32 chooses them: the
+// fewest passes, then the fewest idle slots)
+static int attq_rows_per_pass(int R) {
+  if (R <= 5) return R;
+  int rb = 5, best_passes = 1 << 30, best_waste = 1 << 30;
+  for (int cand = 5; cand >= 3; --cand) {
+    const int passes = ceil_div(R, cand), waste = passes * cand - R;
+    if (passes < best_passes || (passes == best_passes && waste < best_waste)) {
+      best_passes = passes; best_waste = waste; rb = cand;
+    }
+  }
+  return rb;
+}
+
+// R up to ATT_MAX_ROWS rows per group (beams wider than 5 take several passes of 3 to 5 rows)
 bool dense_topk_attq_supported(int R, int L, int U, int D, int H, int top_k) {
-  return dense_topk_attention_supported(R, L, U, D, H, top_k) && U % 128 == 0 && H % 32 == 0 && U <= 512 &&
-         sizeof(float) * attention_lds_floats(512, R, R, L, D) <= 64 * 1024;
+  if (R < 1 || R > ATT_MAX_ROWS || L < 1 || U < 128 || U > 512 || U % 128 || D < 4 || D % 4 || H < 32 || H % 32)
+    return false;
+  if (top_k != (R <= 1 ? 1 : (R <= 3 ? 3 : 5))) return false;
+  return sizeof(float) * attention_lds_floats(512, R, attq_rows_per_pass(R), L, D) <= 64 * 1024;
 }
 
 int dense_topk_attq_tiles(int rows, int U) { return ceil_div(rows, 64) * (U / 128); }
@@ -1806,11 +1823,14 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
   if (tiles_before < 0) tiles_before = 0;
   if (tiles_before > a.tiles_m * a.tiles_n) tiles_before = (a.tiles_m * a.tiles_n) & ~7;
 #define ICAP_ATTQ(TK, RB_) hipLaunchKernelGGL((dense_topk_attq_kernel<TK, RB_>), grid, block, 0, s, a, aq, t, nq, att_blocks, tiles_before, q_done, q_target, err)
-  switch (R) {
+  switch (R <= 5 ? R : 10 + attq_rows_per_pass(R)) {
     case 1: ICAP_ATTQ(1, 1); break;
     case 2: ICAP_ATTQ(3, 2); break;
     case 3: ICAP_ATTQ(3, 3); break;
     case 4: ICAP_ATTQ(5, 4); break;
+    case 5: ICAP_ATTQ(5, 5); break;
+    case 13: ICAP_ATTQ(5, 3); break;  // wider beams: records of 5, passes of 3 to 5 rows
+    case 14: ICAP_ATTQ(5, 4); break;
     default: ICAP_ATTQ(5, 5); break;
   }
 #undef ICAP_ATTQ

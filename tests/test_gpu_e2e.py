@@ -195,6 +195,22 @@ def test_decode_merged_launch_with_query_tiles(monkeypatch, W, qtiles):
         assert nbad == 0
 
 
+@pytest.mark.parametrize("W", [6, 7, 10, 13, 16])
+def test_decode_merged_launch_with_wide_beams(W):
+    """Beams wider than the records are deep take the merged launch too (query tiles; the
+    attention workgroups walk every image's rows in passes of 3, 4 or 5), with the
+    proof-or-repeat beam step behind it; a vocabulary of 600 words leaves some steps to the
+    repeat on full logits."""
+    def setup(eng):
+        assert eng.fused_vocab and eng.merged_launch
+
+    dims = dict(QTILES, V=600)
+    for tile_mode in ("reference", "repeat"):
+        nbad, _ = _compare_decode({}, dims, seed=71 + W, B=12, L=7, T=6, W=W, tile_mode=tile_mode,
+                                  bias_seed=5, setup=setup)
+        assert nbad == 0
+
+
 @pytest.mark.parametrize("W,V", [(3, 1000), (5, 10000)])
 def test_beam_step_inside_the_projection_launch_over_several_tile_rows(monkeypatch, W, V):
     """ICAP_BEAM_IN_LAUNCH=1 with images spread over several 128-row tiles (their workgroups
