@@ -754,7 +754,13 @@ __global__ __launch_bounds__(64 * WL) void beam_records_rows_kernel(RecArgs p) {
 constexpr int WIDE_NT = 1024;
 constexpr int WIDE_CAP = 2048;  // contender slots
 
-template <int WL>
+// ITEMS > 0 (records per lane of a row's wave, HT <= 64 * ITEMS): one pass over the records.
+// Wave w folds row w's statistics and keeps every record's best logit in registers (it is the
+// record's maximum); the bound T comes from the lanes' best scores, and only records whose
+// best logit reaches T are read again in full (their other logits are lower).  ITEMS == 0:
+// any HT, three passes (statistics, bound, contenders) - the records of 256 images do not
+// stay in L2 between passes, so each pass is one over HBM.
+template <int WL, int ITEMS>
 __global__ __launch_bounds__(WIDE_NT) void beam_records_wide_kernel(RecArgs p, int* overflow) {
   constexpr int RL = 2 + 2 * WL;
   constexpr int NWV = WIDE_NT / 64;
@@ -784,6 +790,129 @@ __global__ __launch_bounds__(WIDE_NT) void beam_records_wide_kernel(RecArgs p, i
   }
   if (tid == 0) { l_n = 0; s_over = 0; }
 
+  // the contender test of one record (all of its logits), shared by both forms
+  auto contend = [&](int idx, int w, float thr) {
+    const float4* r4 = reinterpret_cast<const float4*>(rec0 + (size_t)idx * RL);
+    float4 q4[RL / 4];
+#pragma unroll
+    for (int q = 0; q < RL / 4; ++q) q4[q] = r4[q];
+    const float* fl = reinterpret_cast<const float*>(&q4[0]);
+    const float lp = s_lp[w], M = s_M[w], lse = s_L[w];
+    const float pen_oth = penalty_of(p.pen, s_len[w] + 1);
+    const int flat0 = first ? 0 : w * V;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const float x = fl[2 + k];
+      const int col = __float_as_int(fl[2 + WL + k]);
+      const float tot = lp + ((x - M) - lse);
+      const float sc = tot / pen_oth;
+      const bool in_range = col >= 0 && col < V;
+      // (the eos column is scored by its row's synthetic candidate, with its own penalty)
+      if (in_range && sc == sc && sc >= thr) {
+        if (k == WL - 1) s_over = 1;  // the record may hide logits that reach the bound too
+        if (col != p.eos) {
+          const int slot = atomicAdd(&l_n, 1);
+          if (slot < WIDE_CAP) { l_s[slot] = sc; l_t[slot] = tot; l_i[slot] = flat0 + col; }
+        }
+      }
+    }
+  };
+  // the W-th largest of every thread's `tmax`: a lower bound on the W-th best score (W
+  // different candidates reach it)
+  auto bound_of = [&](float tmax) -> float {
+    {
+      float v[1] = {tmax};
+      float top[MAXW];
+      wave_kth_largest<MAXW, 1>(v, lane, top);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) s_top[wave * MAXW + k] = top[k];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int PERV = NWV * MAXW / 64;
+      float v[PERV];
+#pragma unroll
+      for (int q = 0; q < PERV; ++q) v[q] = s_top[lane + 64 * q];
+      // the W-th largest: W rounds, each removing one instance of the maximum
+      float kth = -INFINITY;
+      for (int r = 0; r < W; ++r) {
+        float m = v[0];
+#pragma unroll
+        for (int q = 1; q < PERV; ++q) m = fmaxf(m, v[q]);
+        const float top = wave_max(m);
+        kth = top;
+        const unsigned long long owners = __ballot(m == top);
+        if (owners != 0 && lane == (int)__builtin_ctzll(owners)) {
+          bool done = false;
+#pragma unroll
+          for (int q = 0; q < PERV; ++q)
+            if (!done && v[q] == top) { v[q] = -INFINITY; done = true; }
+        }
+      }
+      if (lane == 0) s_thr = kth;
+    }
+    __syncthreads();
+    return s_thr;  // -inf when fewer than W live candidates exist: everything contends
+  };
+
+  if constexpr (ITEMS > 0) {
+    // ---- A+B in one pass: wave w <- row w, lane <- records lane, lane + 64, ... ----
+    float xs[ITEMS];   // the records' best logits (-inf: no record / no valid column / eos)
+    float tbest = -INFINITY;
+    __syncthreads();   // s_lp, s_len, s_fin
+    if (wave < n_rows) {
+      float2 ms[ITEMS];
+      int c0[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int h = lane + 64 * j;
+        const bool ok = h < HT;
+        const float* r = rec0 + ((size_t)wave * HT + (ok ? h : 0)) * RL;
+        ms[j] = *reinterpret_cast<const float2*>(r);
+        c0[j] = __float_as_int(r[2 + WL]);
+        if (!ok) { ms[j] = make_float2(-INFINITY, 0.f); c0[j] = -1; }
+      }
+      float m = -INFINITY, sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        if (ms[j].x > -INFINITY) {
+          const float nm = fmaxf(m, ms[j].x);
+          sm = sm * fast_exp(m - nm) + ms[j].y * fast_exp(ms[j].x - nm);  // (m = -inf: sm is 0, exp gives 0)
+          m = nm;
+        }
+        // a record's best logit is its maximum; kept while any of its logits could contend
+        xs[j] = (c0[j] >= 0 && c0[j] < V) ? ms[j].x : -INFINITY;
+        if (c0[j] >= 0 && c0[j] < V && c0[j] != p.eos) tbest = fmaxf(tbest, ms[j].x);
+      }
+      const float M = wave_max(m);
+      const float tot = wave_sum((m > -INFINITY) ? sm * fast_exp(m - M) : 0.f);
+      const float L = logf(tot);
+      if (lane == 0) { s_M[wave] = M; s_L[wave] = L; }
+      // the lane's best score: scores grow with the logit inside a row
+      if (!s_fin[wave] && tbest > -INFINITY) {
+        const float sc = (s_lp[wave] + ((tbest - M) - L)) / penalty_of(p.pen, s_len[wave] + 1);
+        tbest = (sc == sc) ? sc : -INFINITY;
+      } else {
+        tbest = -INFINITY;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) xs[j] = -INFINITY;
+    }
+    const float thr = bound_of(tbest);  // (its barriers also publish s_M, s_L)
+    // ---- C: records whose best logit reaches the bound (or is not a number) ----
+    if (wave < n_rows && !s_fin[wave]) {
+      const float lp = s_lp[wave], M = s_M[wave], lse = s_L[wave];
+      const float pen_oth = penalty_of(p.pen, s_len[wave] + 1);
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const float sc0 = (lp + ((xs[j] - M) - lse)) / pen_oth;
+        if (xs[j] > -INFINITY && !(sc0 < thr)) contend(wave * HT + lane + 64 * j, wave, thr);
+      }
+    }
+  } else {
   // ---- A: row statistics, wave w <- row w ----
   if (wave < n_rows) {
     float m = -INFINITY, sm = 0.f;
@@ -813,70 +942,14 @@ __global__ __launch_bounds__(WIDE_NT) void beam_records_wide_kernel(RecArgs p, i
     const float sc = tot / penalty_of(p.pen, s_len[w] + 1);
     if (col >= 0 && col < V && col != p.eos && sc == sc) tmax = fmaxf(tmax, sc);
   }
-  {
-    float v[1] = {tmax};
-    float top[MAXW];
-    wave_kth_largest<MAXW, 1>(v, lane, top);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < MAXW; ++k) s_top[wave * MAXW + k] = top[k];
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    constexpr int PERV = NWV * MAXW / 64;
-    float v[PERV];
-#pragma unroll
-    for (int q = 0; q < PERV; ++q) v[q] = s_top[lane + 64 * q];
-    // the W-th largest: W rounds, each removing one instance of the maximum
-    float kth = -INFINITY;
-    for (int r = 0; r < W; ++r) {
-      float m = v[0];
-#pragma unroll
-      for (int q = 1; q < PERV; ++q) m = fmaxf(m, v[q]);
-      const float top = wave_max(m);
-      kth = top;
-      const unsigned long long owners = __ballot(m == top);
-      if (owners != 0 && lane == (int)__builtin_ctzll(owners)) {
-        bool done = false;
-#pragma unroll
-        for (int q = 0; q < PERV; ++q)
-          if (!done && v[q] == top) { v[q] = -INFINITY; done = true; }
-      }
-    }
-    if (lane == 0) s_thr = kth;
-  }
-  __syncthreads();
-  const float thr = s_thr;  // -inf when fewer than W live candidates exist: everything contends
+  const float thr = bound_of(tmax);
 
   // ---- C: contenders ----
   for (int idx = tid; idx < n_rec; idx += WIDE_NT) {
     const int w = idx / HT;
     if (s_fin[w]) continue;
-    const float4* r4 = reinterpret_cast<const float4*>(rec0 + (size_t)idx * RL);
-    float4 q4[RL / 4];
-#pragma unroll
-    for (int q = 0; q < RL / 4; ++q) q4[q] = r4[q];
-    const float* fl = reinterpret_cast<const float*>(&q4[0]);
-    const float lp = s_lp[w], M = s_M[w], lse = s_L[w];
-    const float pen_oth = penalty_of(p.pen, s_len[w] + 1);
-    const int flat0 = first ? 0 : w * V;
-#pragma unroll
-    for (int k = 0; k < WL; ++k) {
-      const float x = fl[2 + k];
-      const int col = __float_as_int(fl[2 + WL + k]);
-      const float tot = lp + ((x - M) - lse);
-      const float sc = tot / pen_oth;
-      const bool in_range = col >= 0 && col < V;
-      // (the eos column is scored by its row's synthetic candidate, with its own penalty)
-      if (in_range && sc == sc && sc >= thr) {
-        if (k == WL - 1) s_over = 1;  // the record may hide logits that reach the bound too
-        if (col != p.eos) {
-          const int slot = atomicAdd(&l_n, 1);
-          if (slot < WIDE_CAP) { l_s[slot] = sc; l_t[slot] = tot; l_i[slot] = flat0 + col; }
-        }
-      }
-    }
+    contend(idx, w, thr);
+  }
   }
   // synthetic candidates: thread w*(W+2)+j makes the j-th candidate of a finished row w (all
   // its mass on eos: only the first W+1 columns and eos can be selected) and, for j == 0, the
@@ -1260,7 +1333,15 @@ int beam_step_from_records_wide_f32(const float* records, const float* eos_logit
   a.next_lp = next_log_probs; a.next_fin = next_finished; a.next_len = next_lengths;
   a.B = B; a.W = W; a.V = V;
   a.pen = make_penalty(length_penalty_weight);
-  hipLaunchKernelGGL(beam_records_wide_kernel<5>, dim3(B), dim3(WIDE_NT), 0, s, a, overflow);
+  // (ICAP_WIDE_BEAM_FORM=passes: the three-pass form at any size; tuning / test knob)
+  const char* form_env = getenv("ICAP_WIDE_BEAM_FORM");
+  const bool passes = form_env && form_env[0] == 'p';
+  if (!passes && half_tiles <= 64 * 4)
+    hipLaunchKernelGGL((beam_records_wide_kernel<5, 4>), dim3(B), dim3(WIDE_NT), 0, s, a, overflow);
+  else if (!passes && half_tiles <= 64 * 16)
+    hipLaunchKernelGGL((beam_records_wide_kernel<5, 16>), dim3(B), dim3(WIDE_NT), 0, s, a, overflow);
+  else
+    hipLaunchKernelGGL((beam_records_wide_kernel<5, 0>), dim3(B), dim3(WIDE_NT), 0, s, a, overflow);
   ICAP_LAUNCH_CHECK("beam_records_wide_kernel");
   return ICAP_OK;
 }
