@@ -1806,7 +1806,9 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
   aq.tiles_m = ceil_div(rows, 64);
   aq.tiles_n = U / 128;
   const int nq = aq.tiles_m * aq.tiles_n;
-  att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
+  // (work items of the attention: one per image and pass of rows)
+  const int att_items = G * ceil_div(R, attq_rows_per_pass(R));
+  att_blocks = att_blocks > 0 ? (att_blocks < att_items ? att_blocks : att_items) : att_items;
   AttArgs t{pf, features, q, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
             G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
   const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + a.tiles_m * a.tiles_n), block(512);

@@ -484,9 +484,11 @@ int icap_engine_set_overlap(icap_engine* engine, int on);
  * environment when the engine is created overrides).  The logits of the two forms differ by float32 rounding only (both
  * within the 1e-5 bar of the oracle).  ICAP_ERR_UNSUPPORTED in bf16 mode with on != 0. */
 int icap_engine_set_fold_fc(icap_engine* engine, int on);
-/* 1 when the engine carries the next step's query projection and attention in the first
- * workgroups of the vocab projection's launch (fp32 fused path with the folded output kernel;
- * ICAP_MERGED=0|1 in the environment at creation overrides), 0 when they run on the side stream. */
+/* 1 when the engine carries the next step's query projection and attention as workgroups of
+ * the vocab projection's launch (fp32 fused path with the folded output kernel, every beam
+ * width up to ICAP_MAX_BEAM_WIDTH the attention shape fits; ICAP_MERGED=0|1 in the environment
+ * at creation overrides, and =1 also selects the bf16 form of the launch in bf16 mode), 0 when
+ * they run on the side stream. */
 int icap_engine_merged_launch(const icap_engine* engine);
 /* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
  * icap_beam_step_from_records_f32; in bf16 mode the bf16 projection writes the same
