@@ -1153,6 +1153,9 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
       static const char* fused_env2 = getenv("ICAP_FUSED_TOPK");
       if (!fused_env2 && N > 64 && !e->wide && (e->merged || c.precision != ICAP_PRECISION_FP32))
         e->topk = e->topk_able;
+      // wide beams with the merged launch: from 512 rows (beam 16: B = 32 11.1k against 9.9k,
+      // B = 64 16.0k against 13.9k; beam 10: B = 64 19.6k against 18.6k, B = 32 12.7k against 13.8k)
+      if (!fused_env2 && e->wide && e->merged && N >= 512) e->topk = e->topk_able;
     }
     // bf16 mode: the same arrangement around the bf16 record projection (query tiles always),
     // on request only (ICAP_MERGED=1): 152-165k against 176k captions/s on the side stream at
