@@ -1115,8 +1115,13 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     err = hipGetDeviceProperties(&prop, e->device);
     static const char* cap_env = getenv("ICAP_SIDE_ATT_WGS");
     if (err == hipSuccess)
+      // (bf16 mode: uncapped, except beams of 4 and 5 whose images divide evenly over one
+      // workgroup per compute unit - B = 512, beam 5: 188k against 181k captions/s, beam 4: 215k
+      // against 206k; B = 384, beam 5: 151k against 157k; beam 3: 202k against 225k)
       e->side_att_wgs = cap_env ? atoi(cap_env)
-                                : (c.precision == ICAP_PRECISION_BF16 ? 0 : prop.multiProcessorCount);
+                        : c.precision != ICAP_PRECISION_BF16 ? prop.multiProcessorCount
+                        : (c.W >= 4 && c.B % prop.multiProcessorCount == 0) ? prop.multiProcessorCount
+                                                                             : 0;
   }
   {
     // The next step's query + attention inside the projection's launch.  With the folded
