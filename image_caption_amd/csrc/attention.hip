@@ -82,6 +82,23 @@ int dispatch_uch(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
   }
 }
 
+// ---- epf = exp(2 * pf), the step-invariant factor of the tanh scores; *extreme is raised when
+// an entry is too large for the factored form (or not a number) ----
+__global__ __launch_bounds__(256) void att_exp_table_kernel(const float4* __restrict__ pf,
+                                                            float4* __restrict__ epf, int* extreme,
+                                                            size_t n4) {
+  constexpr float C2 = 2.88539008177792681f;  // 2 / ln 2
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 x = pf[i];
+    const float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    bad |= !(m < ATT_EXP_LIMIT);
+    epf[i] = make_float4(__builtin_amdgcn_exp2f(x.x * C2), __builtin_amdgcn_exp2f(x.y * C2),
+                         __builtin_amdgcn_exp2f(x.z * C2), __builtin_amdgcn_exp2f(x.w * C2));
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(extreme, 1);
+}
+
 // ---- pooled[G,D] = mean_L features (or masked sum) ----
 __global__ __launch_bounds__(256) void pool_features_kernel(const float* __restrict__ features,
                                                             const float* __restrict__ mask,
@@ -133,16 +150,18 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
                       float bv, const float* score_bias, const float* gate_state,
                       const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                       int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
-                      int activation, hipStream_t s);
+                      int activation, hipStream_t s, const float* epf = nullptr,
+                      const int* pf_extreme = nullptr);
 
+// epf / pf_extreme: the table exp(2 * pf) and its flag from attention_exp_table_f32 (optional)
 int attention_f32(const float* pf, const float* features, const float* q, const float* v,
                   float bv, const float* score_bias, const float* gate_state,
                   const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                   int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
-                  hipStream_t s) {
+                  hipStream_t s, const float* epf, const int* pf_extreme) {
   return attention_act_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx,
                            weights, G, R, stride_g, stride_k, L, U, D, H, max_workgroups,
-                           ICAP_ATT_ACT_TANH, s);
+                           ICAP_ATT_ACT_TANH, s, epf, pf_extreme);
 }
 
 // activation: ICAP_ATT_ACT_*; anything but tanh serves one row per group (the layer called on
@@ -151,8 +170,10 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
                       float bv, const float* score_bias, const float* gate_state,
                       const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                       int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
-                      int activation, hipStream_t s) {
+                      int activation, hipStream_t s, const float* epf, const int* pf_extreme) {
   ICAP_REQUIRE(pf && features && q && v && ctx, "attention_f32: null pointer");
+  ICAP_REQUIRE((epf == nullptr) == (pf_extreme == nullptr) && (!epf || aligned16(epf)),
+               "attention_f32: the exp table comes with its flag, 16-byte aligned");
   ICAP_REQUIRE(activation >= ICAP_ATT_ACT_TANH && activation <= ICAP_ATT_ACT_SIGMOID,
                "attention_f32: unknown activation %d", activation);
   ICAP_REQUIRE(activation == ICAP_ATT_ACT_TANH || R == 1,
@@ -165,6 +186,8 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
   AttArgs a{pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx, weights,
             G, R, stride_g, stride_k, L, U, D, H,
             0, nullptr, nullptr, nullptr};
+  a.epf = epf;
+  a.pf_extreme = pf_extreme;
   {
     // The kernel's waves raise their instruction-issue priority: beside a matrix kernel on
     // another stream they get out of its way sooner (headline shape 99.2k against 98.7k
@@ -233,6 +256,19 @@ int attention_fq_f32(const float* pf, const float* features, const float* v, flo
     default: hipLaunchKernelGGL(attention_fq_kernel<5>, grid, block, smem, s, a); break;
   }
   ICAP_LAUNCH_CHECK("attention_fq_kernel");
+  return ICAP_OK;
+}
+
+// n = G*L*U floats (a multiple of 4), both buffers 16-byte aligned; *extreme must be 0 before.
+int attention_exp_table_f32(const float* pf, float* epf, int* extreme, size_t n, hipStream_t s) {
+  ICAP_REQUIRE(pf && epf && extreme, "attention_exp_table_f32: null pointer");
+  ICAP_REQUIRE(n > 0 && n % 4 == 0 && aligned16(pf) && aligned16(epf),
+               "attention_exp_table_f32: needs a multiple of 4 floats in 16-byte aligned buffers");
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(att_exp_table_kernel, dim3(grid), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(pf), reinterpret_cast<float4*>(epf), extreme, n4);
+  ICAP_LAUNCH_CHECK("att_exp_table_kernel");
   return ICAP_OK;
 }
 

@@ -7,6 +7,12 @@
 //   phase 1  score[k][l] = sum_u v[u]*tanh(PF[l][u] + q_k[u])  : each wave takes locations
 //            l = wave, wave+WAVES, ...; a lane owns 4 consecutive u per 256-wide chunk, q_k
 //            and v stay in registers; wavefront shuffles reduce over u, scores go to LDS.
+//            tanh(a + b) = 1 - 2 / (1 + exp(2a) * exp(2b)): with exp(2 * PF) tabulated once per
+//            decode (PF does not change over the steps) and exp(2 * q_k) formed once per work
+//            item, an element costs one reciprocal instead of an exponential and a
+//            reciprocal - the two quarter-rate instructions that bound this phase.  The
+//            factors stay finite and normal while |PF| and |q| are below ATT_EXP_LIMIT;
+//            beyond it the work item takes the plain form on PF itself.
 //   phase 2  softmax over l per row (one wave per row), weights kept in LDS.
 //   phase 3  ctx[k][d] = sum_l w[k][l]*F[l][d] : waves split l, lanes own 4 d each; partial
 //            sums meet in LDS; optional sigmoid gate (beta) applied on store.
@@ -37,7 +43,14 @@ struct AttArgs {
   const float* q_w;      // [H,U]
   const float* q_b;      // [U] or null
   int high_prio = 0;     // the kernel's waves raise their issue priority
+  // Factored form of the tanh score (vector path): epf = exp(2 * PF) [G,L,U], built once per
+  // decode, and *pf_extreme != 0 if any |PF| reached ATT_EXP_LIMIT (then the plain form runs).
+  const float* epf = nullptr;
+  const int* pf_extreme = nullptr;
 };
+
+// |x| below this keeps exp(2x) and its reciprocal finite and normal in float32
+constexpr float ATT_EXP_LIMIT = 40.f;
 
 #if defined(__HIPCC__)
 template <bool VEC>
@@ -63,6 +76,8 @@ inline size_t attention_lds_floats(int nt, int R, int rb, int L, int D) {
 }
 
 #if defined(__HIPCC__)
+struct ATT_TRUE { static constexpr bool value = true; };
+struct ATT_FALSE { static constexpr bool value = false; };
 // The activation inside the score: tanh (the reference default, attention/attention.py:31)
 // or one of the other named forms a caller may construct the layer with.
 constexpr int ATT_ACT_TANH = 0, ATT_ACT_LINEAR = 1, ATT_ACT_RELU = 2, ATT_ACT_SIGMOID = 3;
@@ -158,17 +173,51 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
         }
       }
     }
-    auto score_location = [&](const float4 (&x)[UCH], int l) {
+    // factored form: q4 becomes exp(2 q) when this work item may use the table (every wave
+    // holds the same q4, so the decision is the same in all of them)
+    bool factored = false;
+    if constexpr (VEC && ACT == ATT_ACT_TANH) {
+      if (p.epf != nullptr && *p.pf_extreme == 0) {
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int ch = 0; ch < UCH; ++ch)
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(q4[r][ch].x), fabsf(q4[r][ch].y))),
+                       fmaxf(fabsf(q4[r][ch].z), fabsf(q4[r][ch].w)));
+        factored = __builtin_amdgcn_ballot_w64(!(mx < ATT_EXP_LIMIT)) == 0ull;
+        if (factored) {
+          constexpr float C2 = 2.88539008177792681f;  // 2 / ln 2
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int ch = 0; ch < UCH; ++ch) {
+              q4[r][ch].x = __builtin_amdgcn_exp2f(q4[r][ch].x * C2);
+              q4[r][ch].y = __builtin_amdgcn_exp2f(q4[r][ch].y * C2);
+              q4[r][ch].z = __builtin_amdgcn_exp2f(q4[r][ch].z * C2);
+              q4[r][ch].w = __builtin_amdgcn_exp2f(q4[r][ch].w * C2);
+            }
+        }
+      }
+    }
+    const float* x_g = factored ? p.epf + (size_t)g * p.L * p.U : pf_g;
+    // FAST: x holds exp(2 PF) and q4 exp(2 q); tanh = 1 - 2 / (1 + product)
+    auto score_location = [&](const float4 (&x)[UCH], int l, auto fast) {
+      constexpr bool FAST = decltype(fast)::value;
+      auto term = [&](float xv, float qv) -> float {
+        if constexpr (FAST) return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(xv, qv, 1.0f)), 1.0f);
+        else return att_act<ACT>(xv + qv);
+      };
       float a[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         a[r] = 0.f;
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch) {
-          a[r] += v4[ch].x * att_act<ACT>(x[ch].x + q4[r][ch].x);
-          a[r] += v4[ch].y * att_act<ACT>(x[ch].y + q4[r][ch].y);
-          a[r] += v4[ch].z * att_act<ACT>(x[ch].z + q4[r][ch].z);
-          a[r] += v4[ch].w * att_act<ACT>(x[ch].w + q4[r][ch].w);
+          a[r] += v4[ch].x * term(x[ch].x, q4[r][ch].x);
+          a[r] += v4[ch].y * term(x[ch].y, q4[r][ch].y);
+          a[r] += v4[ch].z * term(x[ch].z, q4[r][ch].z);
+          a[r] += v4[ch].w * term(x[ch].w, q4[r][ch].w);
         }
       }
       float part[RB];
@@ -197,17 +246,25 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
       int off[UCH];
 #pragma unroll
       for (int ch = 0; ch < UCH; ++ch) off[ch] = (ch * 256 + lane * 4 + 3 < p.U) ? ch * 256 + lane * 4 : 0;
-      float4 xa[LB][UCH], xb[LB][UCH];
-      att_load_batch<LB, UCH, WAVES>(xa, pf_g, p.U, off, wave, p.L);
-      for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
-        att_load_batch<LB, UCH, WAVES>(xb, pf_g, p.U, off, l0 + STEP, p.L);
+      auto walk = [&](auto fast) {
+        float4 xa[LB][UCH], xb[LB][UCH];
+        att_load_batch<LB, UCH, WAVES>(xa, x_g, p.U, off, wave, p.L);
+        for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
+          att_load_batch<LB, UCH, WAVES>(xb, x_g, p.U, off, l0 + STEP, p.L);
 #pragma unroll
-        for (int b = 0; b < LB; ++b)
-          if (l0 + b * WAVES < p.L) score_location(xa[b], l0 + b * WAVES);
-        att_load_batch<LB, UCH, WAVES>(xa, pf_g, p.U, off, l0 + 2 * STEP, p.L);
+          for (int b = 0; b < LB; ++b)
+            if (l0 + b * WAVES < p.L) score_location(xa[b], l0 + b * WAVES, fast);
+          att_load_batch<LB, UCH, WAVES>(xa, x_g, p.U, off, l0 + 2 * STEP, p.L);
 #pragma unroll
-        for (int b = 0; b < LB; ++b)
-          if (l0 + STEP + b * WAVES < p.L) score_location(xb[b], l0 + STEP + b * WAVES);
+          for (int b = 0; b < LB; ++b)
+            if (l0 + STEP + b * WAVES < p.L) score_location(xb[b], l0 + STEP + b * WAVES, fast);
+        }
+      };
+      if constexpr (ACT == ATT_ACT_TANH) {
+        if (factored) walk(ATT_TRUE{});
+        else walk(ATT_FALSE{});
+      } else {
+        walk(ATT_FALSE{});
       }
     } else {
       for (int l = wave; l < p.L; l += WAVES) {
@@ -215,7 +272,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
 #pragma unroll
         for (int ch = 0; ch < UCH; ++ch)
           x[ch] = att_ld4<VEC>(pf_g + (size_t)l * p.U, ch * 256 + lane * 4, p.U);
-        score_location(x, l);
+        score_location(x, l, ATT_FALSE{});
       }
     }
   }

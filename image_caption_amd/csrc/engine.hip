@@ -97,23 +97,27 @@ int dense_topk_bf16_attq(const void*, const void*, const float*, int, int, int, 
                          const LogitMasks*, const float*, const float*, const float*, float,
                          const float*, const float*, float, const void*, const float*, float*, float*,
                          int, int, int, int, int, int, int, int, int, unsigned*, unsigned, int*,
-                         hipStream_t);
+                         hipStream_t, const float* epf = nullptr, const int* pf_extreme = nullptr);
 int dense_topk_attq_tiles(int rows, int U);
 int dense_topk_attq_f32(const float*, int, const float*, const float*, int, int, int, int, int,
                         float*, float*, const LogitMasks*, const float*, const float*,
                         const float*, float, const float*, const float*, float, const float*,
                         const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                        unsigned*, unsigned, int*, hipStream_t);
+                        unsigned*, unsigned, int*, hipStream_t, const float* epf = nullptr,
+                        const int* pf_extreme = nullptr);
 bool attention_fq_supported(int R, int L, int U, int D, int H);
 int attention_fq_f32(const float*, const float*, const float*, float, const float*, const float*,
                      float, const float*, const float*, float*, int, int, int, int, int, int, int,
                      int, int, hipStream_t);
 int attention_act_f32(const float*, const float*, const float*, const float*, float, const float*,
                       const float*, const float*, float, float*, float*, int, int, int, int, int, int,
-                      int, int, int, int, hipStream_t);
+                      int, int, int, int, hipStream_t, const float* epf = nullptr,
+                      const int* pf_extreme = nullptr);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
-                  int, int, int, hipStream_t);
+                  int, int, int, hipStream_t, const float* epf = nullptr,
+                  const int* pf_extreme = nullptr);
+int attention_exp_table_f32(const float* pf, float* epf, int* extreme, size_t n, hipStream_t s);
 int pool_features_f32(const float*, const float*, float*, int, int, int, hipStream_t);
 int expand_rows_f32(const float*, float*, int, int, int, float, int, hipStream_t);
 int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
@@ -232,6 +236,10 @@ struct icap_engine {
   // counter of finished query tiles (zeroed per decode) and an error word behind it
   bool qtiles = false;
   unsigned* q_done = nullptr;
+  // exp(2 * PF) [B,L,U] and its "too large" flag: the step-invariant factor of the tanh scores
+  // (null: the attention kernels take the plain form; ICAP_ATT_TABLE=0)
+  float* epf = nullptr;
+  int* pf_extreme = nullptr;
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   unsigned timing_mask = 0;  // the caller's selection; `timing` is it or 0, per decode call
@@ -385,6 +393,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     ICAP_TRY(engine_dense(e, icap_engine::PK_W1, features, w.att_w1_kernel, w.att_w1_bias, e->pf,
                           BL, c.D, c.U, ICAP_ACT_NONE, s));
   }
+  if (e->epf) {  // exp(2 PF) for the factored tanh scores of every step's attention
+    Timed t(e, ICAP_K_FEAT_PROJ, s);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, e->pf_extreme, 0, 1);
+    ICAP_LAUNCH_CHECK("fill_i32_kernel");
+    ICAP_TRY(attention_exp_table_f32(e->pf, e->epf, e->pf_extreme, (size_t)BL * c.U, s));
+  }
   LogitMasks masks;
   if (lv.mask_start) masks.start_col = c.start_id;
   if (lv.seq_len) {
@@ -478,7 +492,8 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       Timed tm(e, ICAP_K_ATTENTION, st);
       ICAP_TRY(attention_f32(e->pf, features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
                              state, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
-                             stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st));
+                             stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st, e->epf,
+                             e->pf_extreme));
     }
     return ICAP_OK;
   };
@@ -514,14 +529,14 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                                   e->pk[icap_engine::PK_W2], w.att_w2_bias, e->q, e->ctx, c.B, c.W,
                                   stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
                                   ++q_launches * (unsigned)nq_tiles,
-                                  reinterpret_cast<int*>(e->q_done + 1), s);
+                                  reinterpret_cast<int*>(e->q_done + 1), s, e->epf, e->pf_extreme);
     if (e->qtiles)
       return dense_topk_attq_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk,
                                  e->pf, features, w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel,
                                  e->fc3_bias, w.att_w2_kernel, w.att_w2_bias, e->q, e->ctx, c.B, c.W,
                                  stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
                                  ++q_launches * (unsigned)nq_tiles,
-                                 reinterpret_cast<int*>(e->q_done + 1), s);
+                                 reinterpret_cast<int*>(e->q_done + 1), s, e->epf, e->pf_extreme);
     return dense_topk_attention_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id,
                                     topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
                                     e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
@@ -1031,6 +1046,10 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->tile_rows = ceil_div((int)N, 128);
   const size_t o_trd = cv.take<unsigned>(2 * e->tile_rows + 1);
   const size_t o_qd = cv.take<unsigned>(64);
+  // (ICAP_ATT_TABLE=0, read per engine: no table, the attention kernels evaluate tanh directly)
+  const char* table_env = getenv("ICAP_ATT_TABLE");
+  const bool att_table = !(table_env && table_env[0] == '0') && (BL * c.U) % 4 == 0;
+  const size_t o_epf = cv.take<float>(att_table ? BL * c.U : 0), o_ext = cv.take<int>(64);
   const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
       cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
   const bool gru = c.cell == ICAP_CELL_GRU;
@@ -1214,6 +1233,10 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->flags = (int*)(b + o_flags);
   e->tile_rows_done = (unsigned*)(b + o_trd);
   e->q_done = (unsigned*)(b + o_qd);
+  if (att_table) {
+    e->epf = (float*)(b + o_epf);
+    e->pf_extreme = (int*)(b + o_ext);
+  }
   {
     // opt-in (ICAP_BEAM_IN_LAUNCH=1, read per engine): measured 7 % slower than the separate
     // beam-records kernel at the headline shape

@@ -653,7 +653,7 @@ int dense_topk_bf16_attq(const void* x16, const void* packed_w, const float* bia
                          float gate_b, const void* packed_q_w, const float* q_b, float* q, float* ctx,
                          int G, int R, int stride_g, int stride_k, int L, int U, int D, int H,
                          int att_blocks, unsigned* q_done, unsigned q_target, int* err,
-                         hipStream_t s) {
+                         hipStream_t s, const float* epf, const int* pf_extreme) {
   ICAP_REQUIRE(x16 && packed_w && records && eos_logit, "dense_topk_bf16_attq: null pointer");
   ICAP_REQUIRE(pf && features && att_v && state && gate_w && packed_q_w && q && ctx && q_done && err,
                "dense_topk_bf16_attq: null attention pointer");
@@ -686,6 +686,8 @@ int dense_topk_bf16_attq(const void* x16, const void* packed_w, const float* bia
   att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
   AttArgs t{pf, features, q, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
             G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
+  t.epf = epf;
+  t.pf_extreme = pf_extreme;
   const int tiles = a.tiles_m * a.tiles_n;
   const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + tiles), block(256);
   // Where the attention workgroups sit in the grid (tuning knob ICAP_BF16_ATTQ_TILES_BEFORE):

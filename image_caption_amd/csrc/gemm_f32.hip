@@ -1781,8 +1781,10 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
                         const float* gate_w, float gate_b, const float* q_w, const float* q_b,
                         float* q, float* ctx, int G, int R, int stride_g, int stride_k, int L, int U,
                         int D, int H, int att_blocks, unsigned* q_done, unsigned q_target, int* err,
-                        hipStream_t s) {
+                        hipStream_t s, const float* epf, const int* pf_extreme) {
   ICAP_REQUIRE(x && w && records && eos_logit, "dense_topk_attq_f32: null pointer");
+  ICAP_REQUIRE((epf == nullptr) == (pf_extreme == nullptr) && (!epf || aligned16(epf)),
+               "dense_topk_attq_f32: the exp table comes with its flag, 16-byte aligned");
   ICAP_REQUIRE(pf && features && att_v && state && gate_w && q_w && q && ctx && q_done && err,
                "dense_topk_attq_f32: null attention pointer");
   ICAP_REQUIRE(lda >= K && lda % 4 == 0 && (long long)M * lda < (1LL << 31),
@@ -1811,6 +1813,8 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
   att_blocks = att_blocks > 0 ? (att_blocks < att_items ? att_blocks : att_items) : att_items;
   AttArgs t{pf, features, q, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
             G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
+  t.epf = epf;
+  t.pf_extreme = pf_extreme;
   const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + a.tiles_m * a.tiles_n), block(512);
   // Where the attention workgroups sit in the grid.  In front of every tile they hold one of
   // each compute unit's two slots from the start and the launch ends on a partly filled round

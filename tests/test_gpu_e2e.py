@@ -195,6 +195,39 @@ def test_decode_merged_launch_with_query_tiles(monkeypatch, W, qtiles):
         assert nbad == 0
 
 
+@pytest.mark.parametrize("which", ["att_W1_kernel", "att_W2_kernel", "none"])
+@pytest.mark.parametrize("schedule", ["merged", "side"])
+def test_decode_with_attention_pre_activations_beyond_the_exp_table(monkeypatch, which, schedule):
+    """The attention kernels score with exp(2 PF) tabulated once per decode times exp(2 q); where
+    |PF| or |q| is too large for that product to stay finite and normal (W1 or W2 scaled up)
+    they must take the plain tanh form: same parity bar against the oracle either way, and
+    against the engine without the table."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    monkeypatch.setenv("ICAP_MERGED", "1" if schedule == "merged" else "0")
+    p = _params(QTILES, 91, 5, False)
+    if which != "none":
+        p = dict(p)
+        p[which] = (p[which] * 400.0).astype(np.float32)
+    B, L, T, W = 20, 6, 6, 3
+    img = co.make_images(141, B, L, QTILES["F"])
+    outs = []
+    for table in ("1", "0"):
+        monkeypatch.setenv("ICAP_ATT_TABLE", table)
+        cfg = CaptionConfig(B=B, W=W, L=L, U=QTILES["H"], T=T, start_id=3, eos_id=4, **QTILES)
+        eng = CaptionEngine(cfg, p, device=dev())
+        prefer_fused(eng)
+        assert eng.merged_launch == (schedule == "merged")
+        tok, _ = eng.decode(to_dev(img))
+        tr = {k: np_of(v) for k, v in eng.trace().items()}
+        tok = np_of(tok)
+        eng.close()
+        check_decode_following(p, img, W, T, 3, 4, 1.0, "reference", tok, tr)
+        outs.append((tok, tr))
+    if which == "att_W1_kernel":     # the table is flagged as a whole: both engines evaluated tanh directly
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1]["log_probs"], outs[1][1]["log_probs"])
+
+
 @pytest.mark.parametrize("W", [6, 7, 10, 13, 16])
 def test_decode_merged_launch_with_wide_beams(W):
     """Beams wider than the records are deep take the merged launch too (query tiles; the
