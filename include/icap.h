@@ -393,7 +393,11 @@ typedef struct icap_engine icap_engine;
 
 /* Allocates the workspace for one (device, config) pair on the current device and
  * reads the scalar biases (att_v_bias, fc3_bias) back once.  One engine serves one
- * stream at a time; distinct engines are independent. */
+ * stream at a time; distinct engines are independent.  The workspace includes a [B,L,U] table
+ * exp(2 (W1 features + b1)), rebuilt in every decode, from which the attention scores
+ * (attention/attention.py:47-50) take tanh(a + b) = 1 - 2 / (1 + exp(2a) exp(2b)) with one
+ * reciprocal per element; pre-activations of magnitude 40 and more are scored with tanh itself
+ * (ICAP_ATT_TABLE=0 in the environment at creation: no table). */
 int icap_engine_create(const icap_config* config, const icap_weights* weights,
                        icap_engine** out);
 int icap_engine_destroy(icap_engine* engine);
