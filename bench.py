@@ -126,6 +126,34 @@ def cpu_baseline(cfg, budget_s=12.0):
                             "the reference loop"}
 
 
+def cpu_baseline_config1_torch(cfg):
+    """The CPU figure of the greedy configuration (BASELINE.json configs[0]): B = 32 images,
+    beam 1, same dims / vocabulary / steps, on the torch-CPU op-for-op restatement of the
+    reference loop (oracle/torch_cpu_reference.py: W1(features) every step, tiled features,
+    full [B,W,V] masks, per-row gathers); 3 warm-up + 10 timed whole-batch decodes, median."""
+    import statistics
+    from oracle import caption_oracle as co
+    from oracle import torch_cpu_reference as tr
+    threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16))
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        p = tr.to_torch(co.make_params(0, cfg["F"], cfg["D"], cfg["E"], cfg["H"], cfg["V"]))
+        img = torch.from_numpy(co.make_images(1, 32, cfg["L"], cfg["F"]))
+        times = []
+        for i in range(13):
+            t0 = time.perf_counter()
+            tr.predict_image_caption_sequence(p, img, 1, cfg["T"], 3, 4)
+            if i >= 3:
+                times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(before)
+    return {"value": round(32 / statistics.median(times), 2), "unit": "captions/s", "cores": threads,
+            "kind": "port",
+            "sample": "greedy, B=32, %d steps, V=%d: 3 warm-up + 10 timed decodes, median; torch-CPU "
+                      "op-for-op restatement of the reference loop" % (cfg["T"], cfg["V"])}
+
+
 def cpu_baseline_searcher(cfg, budget_s):
     """The oracle's restatement of the searcher loop on B=32 encoded feature maps."""
     from oracle import caption_oracle as co
@@ -293,6 +321,10 @@ def main():
                     help="decode passes per bench step (0: the configuration's default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --ranks-share-gpu rehearses the multi-rank path on one GPU")
+    ap.add_argument("--gather", default="every", choices=["every", "end"],
+                    help="with N > 1: all-gather the decoded sequences after every decode pass "
+                         "(default) or once, after the last pass of a step - separates decode time "
+                         "from collective time in a scaling run")
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="every rank uses cuda:0 (rehearsal on a one-GPU box, gloo only)")
     args = ap.parse_args()
@@ -357,7 +389,10 @@ def main():
                 eng.search_baseline(feats[j], out=tokens, scores=scores)
             else:
                 eng.decode(imgs[j], out=tokens, scores=scores)
-            out = all_gather_sequences(tokens) if world > 1 else tokens
+            if world > 1 and (args.gather == "every" or j == inner - 1):
+                out = all_gather_sequences(tokens)
+            else:
+                out = tokens
         return out
 
     def sync():
@@ -378,8 +413,11 @@ def main():
         out = step()
     sync()
     elapsed = time.perf_counter() - t0
+    eng.raise_if_invalid()      # (outside the timed region: a decode whose in-launch wait ran out is no result)
     vocab_ms, vocab_n = eng.kernel_times()["vocab"]
     merged_launch = getattr(eng, "merged_launch", False)
+    what_ran = {"fold_fc": eng.fold_fc, "merged_launch": bool(merged_launch), "att_table": eng.att_table,
+                "fused_vocab": eng.fused_vocab}
     eng.set_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -479,7 +517,8 @@ def main():
                        "beam_width": cfg["W"],
                        "decode_steps": cfg["T"], "locations": cfg["L"], "feature_dim": cfg["F"],
                        "hidden": cfg["H"], "vocab": cfg["V"], "tile_mode": args.tile_mode,
-                       "sharding": "images split over ranks, all-gather of sequences"},
+                       "sharding": "images split over ranks, all-gather of sequences",
+                       "gather": args.gather, **what_ran},
             "roofline": roof,
             "hbm_kernels": {"beam_step_GBps": round(beam_gbs, 1),
                             "beam_step_path": "top-k records of the fused projection" if fused
@@ -489,9 +528,8 @@ def main():
             "kernel_ms_per_decode_pass": {k: round(v[0] / diag_steps, 4) for k, v in ktimes.items()},
             "ms_per_decode_pass": round(elapsed / args.steps / inner * 1e3, 4),
         }
-        if world > 1:
-            line["world_size_reported_by_backend"] = dist.get_world_size()
-            line["backend"] = args.backend
+        line["world_size_reported_by_backend"] = dist.get_world_size() if world > 1 else 1
+        line["backend"] = args.backend if world > 1 else "none"
         if world == 1 and precision == "fp32" and loop == "decode" and not args.no_cpu_baseline:
             # informational, not `value`: the same workload with the opt-in precision modes
             # (measured before the CPU baseline, while the GPU clocks are still up)
@@ -511,8 +549,27 @@ def main():
                 other[mode + "_captions_per_s"] = round(10 * cfg["B"] / (time.perf_counter() - t1), 1)
                 e2.close()
             line["other_precision_modes"] = other
+            if what_ran["fold_fc"]:
+                # the reference's op order for the output layer: fc1, then fc2
+                # (decoder/lstm_recurrent_decoder.py:106-112) instead of the folded kernel
+                e3 = CaptionEngine(ccfg, p, device=device)
+                e3.set_fold_fc(False)
+                for _ in range(10):
+                    e3.decode(img, out=tokens, scores=scores)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    e3.decode(imgs[_ % inner], out=tokens, scores=scores)
+                torch.cuda.synchronize()
+                line["fp32_two_products_captions_per_s"] = round(20 * cfg["B"] / (time.perf_counter() - t1), 1)
+                line["fp32_two_products_note"] = ("same engine with fc1 and fc2 as two products, the "
+                                                  "reference's op order (set_fold_fc(False)); `value` "
+                                                  "runs the folded fc1 . fc2 kernel")
+                e3.close()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dict(cfg, loop=loop))
+            if loop == "decode" and cfg.get("cell", "lstm") == "lstm":
+                line["cpu_baseline_config1_torch"] = cpu_baseline_config1_torch(cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

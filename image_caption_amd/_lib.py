@@ -155,6 +155,10 @@ SIGNATURES = {
     "icap_engine_set_overlap": ([_P, _I], C.c_int),
     "icap_engine_set_fold_fc": ([_P, _I], C.c_int),
     "icap_engine_merged_launch": ([_P], C.c_int),
+    "icap_engine_fold_fc": ([_P], C.c_int),
+    "icap_engine_att_table": ([_P], C.c_int),
+    "icap_engine_decode_status": ([_P, C.POINTER(C.c_int32), _P], C.c_int),
+    "icap_engine_debug_sync_state": ([_P, _P, C.POINTER(C.c_int32)], C.c_int),
     "icap_engine_set_fused_vocab": ([_P, _I], C.c_int),
     "icap_engine_fused_vocab": ([_P], C.c_int),
     "icap_engine_kernel_times": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)], C.c_int),

@@ -11,8 +11,8 @@
 //            decode (PF does not change over the steps) and exp(2 * q_k) formed once per work
 //            item, an element costs one reciprocal instead of an exponential and a
 //            reciprocal - the two quarter-rate instructions that bound this phase.  The
-//            factors stay finite and normal while |PF| and |q| are below ATT_EXP_LIMIT;
-//            beyond it the work item takes the plain form on PF itself.
+//            factored form is used while |PF| and |q| are below ATT_EXP_LIMIT (an accuracy
+//            bound, see there); beyond it the work item takes the plain form on PF itself.
 //   phase 2  softmax over l per row (one wave per row), weights kept in LDS.
 //   phase 3  ctx[k][d] = sum_l w[k][l]*F[l][d] : waves split l, lanes own 4 d each; partial
 //            sums meet in LDS; optional sigmoid gate (beta) applied on store.
@@ -49,8 +49,13 @@ struct AttArgs {
   const int* pf_extreme = nullptr;
 };
 
-// |x| below this keeps exp(2x) and its reciprocal finite and normal in float32
-constexpr float ATT_EXP_LIMIT = 40.f;
+// The factored form is used while |PF| and |q| stay below this.  exp(2x) is exp2(x * 2/ln 2);
+// the rounding of that product alone gives the factor a relative error of about 1.2e-7 * |x|,
+// and where PF and q cancel, tanh picks up half the relative error of the product of the two
+// factors: at most about 1.2e-6 at the limit (1e-7 for tanh evaluated directly), and in
+// proportion below it - a few 1e-7 at the pre-activations of a trained model.  (Overflow is
+// far away: the factors stay finite and normal up to |x| = 40.)
+constexpr float ATT_EXP_LIMIT = 10.f;
 
 #if defined(__HIPCC__)
 template <bool VEC>

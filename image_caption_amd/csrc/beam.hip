@@ -1179,15 +1179,28 @@ constexpr int MAX_DEVICES = 64;
 std::mutex scratch_mutex;
 void* scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` per device ordinal
 
-// The device address of the array on the current device, looked up once per device (the
-// array's name is only a host-side handle; kernels get this pointer as an argument).
-int static_scratch(void** out) {
-  int dev = -1;
-  ICAP_HIP(hipGetDevice(&dev));
+// The device address of the array on the device of stream `s`, looked up once per device (the
+// array's name is only a host-side handle; kernels get this pointer as an argument).  The
+// lookup is a runtime call that may load the code object on its first use, so it must not
+// happen under stream capture: the first call on a device has to come from outside a capture.
+int static_scratch(hipStream_t s, void** out) {
+  int dev = -1, cur = -1;
+  ICAP_HIP(hipGetDevice(&cur));
+  if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = cur;
+  }
   ICAP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "beam_step_static_f32: device ordinal %d not served",
                dev);
+  ICAP_REQUIRE(dev == cur, "beam_step_static_f32: the stream belongs to device %d, the current device is %d",
+               dev, cur);
   std::lock_guard<std::mutex> lock(scratch_mutex);
   if (!scratch_ptr[dev]) {
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capture) != hipSuccess) (void)hipGetLastError();
+    ICAP_REQUIRE(capture == hipStreamCaptureStatusNone,
+                 "beam_step_static_f32: the first call on a device looks the static workspace's address up "
+                 "and must be made outside stream capture (device %d)", dev);
     void* p = nullptr;
     ICAP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     ICAP_REQUIRE(p != nullptr, "beam_step_static_f32: no device address for the static workspace");
@@ -1211,7 +1224,7 @@ int beam_step_static_f32(const float* logits, const float* log_probs, const uint
                 "icap_beam_step_f32 with a caller workspace",
                 (long long)B * W, ICAP_BEAM_STEP_STATIC_MAX_ROWS);
   void* ws = nullptr;
-  const int rc = static_scratch(&ws);
+  const int rc = static_scratch(s, &ws);
   if (rc != ICAP_OK) return rc;
   // every slot the merge kernel reads is written by the row kernel of the same call (statistics
   // and all WL candidate slots of every row, empty ones marked), so nothing needs clearing

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -154,9 +155,11 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-// start tokens and the initial beam state (zeros, beam_search.py:85-98) in one launch: a
-// kernel rather than memset calls, whose nodes in a captured graph did not reliably run
-// before the first step's kernels on replays after the first
+// start tokens and the initial beam state (zeros, beam_search.py:85-98) in one launch and one
+// graph node instead of four memset calls.  (An earlier form with memset calls returned stale
+// state on replays of a captured decode after the first; a stand-alone graph of memset nodes
+// in front of a kernel, tools/lab/graph_memset_lab.hip, runs them on every replay, so that
+// symptom stays unexplained - the kernel form has no such node.)
 __global__ void init_beam_state_kernel(int32_t* start_ids, int32_t start_id, float* lp, int32_t* len,
                                        uint8_t* fin, int n, unsigned* words2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +173,50 @@ __global__ void init_beam_state_kernel(int32_t* start_ids, int32_t start_id, flo
 }
 }  // namespace
 
+}  // namespace icap
+
+namespace icap {
+// ONE side stream per device for every engine of the process, created with the first engine on
+// that device and kept until the process ends.  A stream of a priority class of its own costs
+// the process a hardware queue of its own, and the HIP runtime shares hardware queues between
+// streams only within a priority class, GPU_MAX_HW_QUEUES (4) per class: an engine-owned
+// stream per engine made the fifth hardware queue of a process as soon as two engines were
+// alive beside three streams of the caller.  On this runtime (ROCm 7.0 / 7.2, reproduced
+// without this library by tools/lab/null_stream_forkjoin_lab.hip) a decode whose legacy
+// default (null) stream and fifth queue wait on each other's events never finishes: the
+// queues stop consuming packets although every wait has its signal queued.  With one shared
+// stream the library adds one queue per device whatever the number of engines.  Engines that
+// decode at the same time on different streams interleave their side work on it; every piece
+// waits only for an event recorded before it was enqueued, so the interleaving is ordered
+// correctly and cannot deadlock, it merely serialises the side work of concurrent engines.
+hipError_t shared_side_stream(int device, hipStream_t* out) {
+  constexpr int MAX_DEVICES = 64;
+  static std::mutex mu;
+  static hipStream_t streams[MAX_DEVICES] = {};
+  if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!streams[device]) {
+    // The side stream carries work that is off the critical path: the lowest priority lets
+    // its workgroups fill the compute units the main stream leaves idle (small launches, kernel
+    // tails) instead of competing with the vocab projection.  ICAP_SIDE_PRIORITY=default|high
+    // (read once per device) selects another class.
+    int prio_low = 0, prio_high = 0;
+    hipError_t err = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (err != hipSuccess) return err;
+    const char* prio_env = getenv("ICAP_SIDE_PRIORITY");
+    if (prio_env && prio_env[0] == 'd')
+      err = hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+    else
+      err = hipStreamCreateWithPriority(&streams[device], hipStreamNonBlocking,
+                                        prio_env && prio_env[0] == 'h' ? prio_high : prio_low);
+    if (err != hipSuccess) {
+      streams[device] = nullptr;
+      return err;
+    }
+  }
+  *out = streams[device];
+  return hipSuccess;
+}
 }  // namespace icap
 
 struct icap_engine {
@@ -224,7 +271,8 @@ struct icap_engine {
   // keep the two-step form.
   float *w12 = nullptr, *b12 = nullptr;
   bool fold = false;
-  // side stream: the next step's attention runs beside the current step's vocab/beam work
+  // side stream (the device's shared one, see shared_side_stream): the next step's attention
+  // runs beside the current step's vocab/beam work
   hipStream_t side = nullptr;
   hipEvent_t ev_lstm = nullptr, ev_att = nullptr, ev_gate = nullptr;
   bool overlap = true;  // false: everything on the caller's stream (clean per-kernel timing)
@@ -240,6 +288,10 @@ struct icap_engine {
   // (null: the attention kernels take the plain form; ICAP_ATT_TABLE=0)
   float* epf = nullptr;
   int* pf_extreme = nullptr;
+  // The device word that the last enqueued decode's in-launch hand-over raises when one of its
+  // bounded waits ran out (null: that decode had no such wait); icap_engine_decode_status reads it
+  int* last_err = nullptr;
+  bool force_timeout = false;  // test hook (ICAP_MERGED_FORCE_TIMEOUT=1): the waits can never be met
   // timing
   unsigned timing = 0;  // bit k set: launches of kernel class k are bracketed by events
   unsigned timing_mask = 0;  // the caller's selection; `timing` is it or 0, per decode call
@@ -500,15 +552,10 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   // Exact-f32 fused path: query_{t+1} + attention_{t+1} are the first workgroups of the
   // vocab_t launch instead (dense_topk_attention_f32), everything on the caller's stream:
   //   main: lstm_t -> fc1_t -> [attention_{t+1} | vocab_t] -> beam_t -> lstm_{t+1} ...
-  // (a decode that is being captured into a graph keeps the fork / join schedule: after a
-  // capture of the merged schedule, side-stream decodes of other engines of the process were
-  // seen to hang on their event waits)
-  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(s, &capture);
+  // (the same schedule whether or not the stream is being captured into a graph)
   const bool bf16 = c.precision == ICAP_PRECISION_BF16;
   // (bf16 mode: the merged launch takes the row-major bf16 activations fc1 hands over)
   const bool merged = e->merged && e->overlap && topk != 0 &&
-                      capture == hipStreamCaptureStatusNone &&
                       (!bf16 || (e->a16 && !dense_topk_bf16_a16_blocked(N, c.H, c.V, topk)));
   const bool side = e->overlap && !merged;
   const int att_blocks = e->side_att_wgs > 0 ? e->side_att_wgs : c.B;
@@ -528,14 +575,14 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                                   w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel, e->fc3_bias,
                                   e->pk[icap_engine::PK_W2], w.att_w2_bias, e->q, e->ctx, c.B, c.W,
                                   stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
-                                  ++q_launches * (unsigned)nq_tiles,
+                                  e->force_timeout ? ~0u : ++q_launches * (unsigned)nq_tiles,
                                   reinterpret_cast<int*>(e->q_done + 1), s, e->epf, e->pf_extreme);
     if (e->qtiles)
       return dense_topk_attq_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id, topk, e->rec, e->eos_x, mk,
                                  e->pf, features, w.att_v_kernel, e->att_v_bias, state, w.fc3_kernel,
                                  e->fc3_bias, w.att_w2_kernel, w.att_w2_bias, e->q, e->ctx, c.B, c.W,
                                  stride_g, stride_k, c.L, c.U, c.D, c.H, att_blocks, e->q_done,
-                                 ++q_launches * (unsigned)nq_tiles,
+                                 e->force_timeout ? ~0u : ++q_launches * (unsigned)nq_tiles,
                                  reinterpret_cast<int*>(e->q_done + 1), s, e->epf, e->pf_extreme);
     return dense_topk_attention_f32(x, lda, vw, vb, rows, c.H, c.V, c.eos_id,
                                     topk, e->rec, e->eos_x, mk, e->pf, features, w.att_v_kernel,
@@ -741,11 +788,12 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   }
   {  // K10
     Timed tm(e, ICAP_K_BACKTRACK, s);
-    // (a beam step inside a projection launch that could not be taken invalidates the result)
+    // (a hand-over inside a projection launch whose wait ran out invalidates the result: every
+    // token -1, every score NaN, and icap_engine_decode_status reports it)
+    e->last_err = beam_in_launch ? beam_err
+                  : (merged && e->qtiles) ? reinterpret_cast<int*>(e->q_done + 1) : nullptr;
     ICAP_TRY(backtrack_guarded(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N,
-                               fin, tokens, nullptr, best_score, c.T, c.B, c.W,
-                               beam_in_launch ? beam_err
-                               : (merged && e->qtiles) ? reinterpret_cast<int*>(e->q_done + 1) : nullptr, s));
+                               fin, tokens, nullptr, best_score, c.T, c.B, c.W, e->last_err, s));
   }
   return ICAP_OK;
 }
@@ -1108,22 +1156,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->ws_bytes = (cv.off + 255) / 256 * 256;
   hipError_t err = hipGetDevice(&e->device);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->ws), e->ws_bytes);
-  if (err == hipSuccess) {
-    // The side stream carries work that is off the critical path: give it the lowest
-    // priority so that its workgroups fill the compute units the main stream leaves idle
-    // (small launches, kernel tails) instead of competing with the vocab projection.
-    int prio_low = 0, prio_high = 0;
-    err = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    static const char* prio_env = getenv("ICAP_SIDE_PRIORITY");  // tuning knob: "default", "high"
-    if (err == hipSuccess) {
-      if (prio_env && prio_env[0] == 'd')
-        err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-      else if (prio_env && prio_env[0] == 'h')
-        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_high);
-      else
-        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_low);
-    }
-  }
+  if (err == hipSuccess) err = shared_side_stream(e->device, &e->side);  // (owned by the library, not the engine)
   if (err == hipSuccess) {
     // beside the exact-f32 vocab projection the attention kernel gets one workgroup per
     // compute unit, which leaves the projection its two workgroups per CU (96.8k captions/s
@@ -1160,6 +1193,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     // the query projection as tiles of the same launch (ICAP_MERGED_QTILES=0: inside every
     // attention workgroup instead, beams up to 5); wide beams take the tiles form only
     const char* qt_env = getenv("ICAP_MERGED_QTILES");
+    const char* ft_env = getenv("ICAP_MERGED_FORCE_TIMEOUT");  // test hook, read per engine
+    e->force_timeout = ft_env && ft_env[0] == '1';
     e->qtiles = base_ok && !(qt_env && qt_env[0] == '0') &&
                 dense_topk_attq_supported(c.W, c.L, c.U, c.D, c.H, e->topk_able);
     e->merged = e->qtiles ||
@@ -1199,7 +1234,6 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     if (e->ev_gate) (void)hipEventDestroy(e->ev_gate);
     if (e->ev_att) (void)hipEventDestroy(e->ev_att);
     if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
-    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ws) (void)hipFree(e->ws);
     delete e;
     return fail(ICAP_ERR_HIP, "icap_engine_create: %s", hipGetErrorString(err));
@@ -1332,7 +1366,6 @@ int icap_engine_destroy(icap_engine* e) {
   if (e->ev_gate) (void)hipEventDestroy(e->ev_gate);
   if (e->ev_att) (void)hipEventDestroy(e->ev_att);
   if (e->ev_lstm) (void)hipEventDestroy(e->ev_lstm);
-  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->ws) (void)hipFree(e->ws);
   delete e;
   return ICAP_OK;
@@ -1439,6 +1472,35 @@ int icap_engine_set_overlap(icap_engine* e, int on) {
 
 int icap_engine_merged_launch(const icap_engine* e) {
   return e && e->merged && e->overlap && e->topk != 0 ? 1 : 0;
+}
+
+int icap_engine_fold_fc(const icap_engine* e) { return e && e->fold && e->w12 ? 1 : 0; }
+
+int icap_engine_att_table(const icap_engine* e) { return e && e->epf ? 1 : 0; }
+
+int icap_engine_decode_status(icap_engine* e, int32_t* invalid, icap_stream_t stream) {
+  ICAP_REQUIRE(e && invalid, "icap_engine_decode_status: null argument");
+  *invalid = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (e->last_err) {
+    int word = 0;
+    ICAP_HIP(hipMemcpyAsync(&word, e->last_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    ICAP_HIP(hipStreamSynchronize(s));
+    *invalid = word != 0;
+  } else {
+    ICAP_HIP(hipStreamSynchronize(s));
+  }
+  return ICAP_OK;
+}
+
+int icap_engine_debug_sync_state(const icap_engine* e, icap_stream_t stream, int32_t state[4]) {
+  ICAP_REQUIRE(e && state, "icap_engine_debug_sync_state: null argument");
+  state[0] = (int32_t)hipStreamQuery((hipStream_t)stream);
+  state[1] = (int32_t)hipStreamQuery(e->side);
+  state[2] = (int32_t)hipEventQuery(e->ev_lstm);
+  state[3] = (int32_t)hipEventQuery(e->ev_att);
+  (void)hipGetLastError();  // hipErrorNotReady is an answer here, not an error to keep
+  return ICAP_OK;
 }
 
 int icap_engine_set_fold_fc(icap_engine* e, int on) {

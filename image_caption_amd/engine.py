@@ -37,6 +37,10 @@ GRU_PARAM_TO_FIELD.update({"gru_kernel": "lstm_kernel",
                            "gru_bias": "lstm_bias"})
 
 
+class InvalidDecode(RuntimeError):
+    """A decode whose result the device marked invalid (tokens -1, scores NaN)."""
+
+
 @dataclass
 class CaptionConfig:
     """Shapes and decoding constants of one engine (defaults = the reference script:
@@ -165,8 +169,10 @@ class CaptionEngine:
     def workspace_bytes(self):
         return int(_lib.load().icap_engine_workspace_bytes(self._handle))
 
-    def decode(self, img, out=None, scores=None):
-        """img [B,L,F] float32 on the engine's device -> (tokens [B,T] int32, scores [B])."""
+    def decode(self, img, out=None, scores=None, check=False):
+        """img [B,L,F] float32 on the engine's device -> (tokens [B,T] int32, scores [B]).
+        check=True waits for the decode and raises InvalidDecode if the hand-over inside the
+        merged launch ran out of its bounded wait (see decode_invalid)."""
         c = self.config
         if tuple(img.shape) != (c.B, c.L, c.F):
             raise ValueError("img must have shape %s" % ((c.B, c.L, c.F),))
@@ -179,7 +185,23 @@ class CaptionEngine:
         ops._call("icap_decode", self._handle, ops._chk(img, torch.float32, "img"),
                   ops._chk(out, torch.int32, "out"), ops._chk(scores, torch.float32, "scores"),
                   ops.current_stream())
+        if check:
+            self.raise_if_invalid()
         return out, scores
+
+    def decode_invalid(self):
+        """Waits for the current stream and reports whether the last decode was invalidated on
+        the device: a bounded wait of the in-launch hand-over ran out, every token is -1 and
+        every score NaN (never observed in normal operation; icap_engine_decode_status)."""
+        flag = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.call("icap_engine_decode_status", self._handle, C.byref(flag), self._stream())
+        return bool(flag.value)
+
+    def raise_if_invalid(self):
+        if self.decode_invalid():
+            raise InvalidDecode("the decode was invalidated on the device: a wait inside the merged "
+                                "launch ran out; its tokens are -1")
 
     def _same_device(self, **tensors):
         for name, t in tensors.items():
@@ -236,6 +258,16 @@ class CaptionEngine:
     def merged_launch(self):
         """True when the next step's query + attention ride in the vocab projection's launch."""
         return bool(_lib.load().icap_engine_merged_launch(self._handle))
+
+    @property
+    def fold_fc(self):
+        """True when the folded fc1 . fc2 kernel projects the cell output."""
+        return bool(_lib.load().icap_engine_fold_fc(self._handle))
+
+    @property
+    def att_table(self):
+        """True when the attention scores use the per-decode exp(2 PF) table."""
+        return bool(_lib.load().icap_engine_att_table(self._handle))
 
     def set_fold_fc(self, on):
         """True (default in fp32 / split mode): project the cell output with the folded

@@ -5,6 +5,7 @@ tensors (ROCm device, dtype, contiguity, shape) and hands raw device pointers pl
 the current HIP stream to the C ABI."""
 from __future__ import annotations
 
+import sys
 import threading
 
 import torch
@@ -34,6 +35,7 @@ def current_stream():
         dev = next(iter(devs)) if devs else torch.device("cuda", torch.cuda.current_device())
     finally:
         devs.clear()
+        _tls.frame = None
     _tls.dev = dev
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -61,6 +63,16 @@ def _chk(t, dtype, name):
     except Exception:
         _pending().clear()
         raise
+    # Operands are collected per operator call, i.e. per frame of the calling operator: a set
+    # left behind by a call whose argument list raised between two checks (and so never
+    # reached current_stream()) belongs to another frame and is dropped here instead of
+    # being mixed into this call's devices.
+    frame = sys._getframe(1)
+    if frame.f_code is _opt.__code__:
+        frame = frame.f_back
+    if getattr(_tls, "frame", None) is not frame:
+        _pending().clear()
+        _tls.frame = frame
     _pending().add(t.device)
     return t.data_ptr()
 
@@ -227,7 +239,7 @@ def logit_masks(logits, start_token=-1, row_len=None, step_plus_1=0, eos_token=-
 def position_table(length, hidden, device):
     """[length, hidden] sinusoid position encoding (RelativePositionEmbedding)."""
     t = torch.empty(length, hidden, dtype=f32, device=device)
-    _call("icap_position_table_f32", t.data_ptr(), int(length), int(hidden), current_stream())
+    _call("icap_position_table_f32", _chk(t, f32, "table"), int(length), int(hidden), current_stream())
     return t
 
 

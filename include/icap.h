@@ -252,9 +252,12 @@ int icap_beam_step_rows_f32(const float* logits, const float* log_probs,
  * icap_beam_step_f32 without the workspace pair: the candidate workspace is a fixed array
  * in device memory (ICAP_BEAM_STEP_STATIC_MAX_ROWS rows of 200 bytes = 3.2 MB, held by every
  * GPU the library runs on until the process ends).  B*W above that limit returns
- * ICAP_ERR_UNSUPPORTED.  The call allocates nothing; the first call on a device looks the
- * array's device address up once.  All calls on one GPU share the array: calls that overlap
- * in time on one GPU (two streams) race - order them or use icap_beam_step_f32. */
+ * ICAP_ERR_UNSUPPORTED.  The call allocates nothing.  The FIRST call on a device looks the
+ * array's device address up (one runtime query, kept per device) and must therefore be made
+ * outside stream capture, with the stream's device current - any valid call serves as that
+ * warm-up; a first call under capture returns ICAP_ERR_INVALID.  Every later call on that
+ * device only enqueues and may be captured.  All calls on one GPU share the array: calls that
+ * overlap in time on one GPU (two streams) race - order them or use icap_beam_step_f32. */
 #define ICAP_BEAM_STEP_STATIC_MAX_ROWS 16384
 int icap_beam_step_static_f32(const float* logits, const float* log_probs,
                               const uint8_t* finished, const int32_t* lengths,
@@ -494,6 +497,36 @@ int icap_engine_set_fold_fc(icap_engine* engine, int on);
  * at creation overrides, and =1 also selects the bf16 form of the launch in bf16 mode), 0 when
  * they run on the side stream. */
 int icap_engine_merged_launch(const icap_engine* engine);
+/* The current choices behind icap_engine_set_fold_fc (1: the folded fc1 . fc2 kernel projects
+ * the cell output) and ICAP_ATT_TABLE (1: the attention scores use the exp(2 PF) table).  No
+ * counterpart in the reference; they exist so that a benchmark line can say what it ran. */
+int icap_engine_fold_fc(const icap_engine* engine);
+int icap_engine_att_table(const icap_engine* engine);
+/* Validity of the last decode enqueued on this engine (icap_decode / icap_search_baseline).
+ * The merged launch (icap_engine_merged_launch) hands the query projection q over INSIDE one
+ * launch: its query tiles store q through to device scope and count themselves on a device
+ * counter, and the attention workgroups of the same launch poll that counter before they read
+ * q.  That is deadlock-free only because workgroups are dispatched in grid order and the query
+ * tiles come first in the grid - true of this hardware's dispatcher, not an architectural
+ * promise - so the poll is bounded (2^16 polls, a fraction of a second): a workgroup whose
+ * wait runs out raises a device word and leaves its rows untouched, and the back-tracking
+ * kernel then writes -1 into every token and NaN into every score instead of a wrong caption.
+ * (The accesses are relaxed device-scope atomics with an explicit wait for the stores'
+ * acknowledgement in front of the count: release / acquire fences at device scope write back
+ * and invalidate a whole L2 under the running tiles and were measured at 232 instead of
+ * 156 microseconds per launch.)  The call returns ICAP_OK either way, as every enqueueing call does;
+ * this function copies the word back behind the decode on `stream` (the decode's stream or one
+ * ordered after it), WAITS for the stream and sets *invalid to 1 when a wait ran out, else 0
+ * (always 0 for decodes without such a hand-over).  A caller that hands tokens on should either
+ * call it once per decode at its next synchronisation point or test the tokens for -1.
+ * ICAP_MERGED_FORCE_TIMEOUT=1 in the environment at engine creation makes every wait
+ * unmeetable (test knob).  No counterpart in the reference (its loop has no such hand-over,
+ * recurrent_example.py:517-558). */
+int icap_engine_decode_status(icap_engine* engine, int32_t* invalid, icap_stream_t stream);
+/* Diagnostics of a decode that does not finish: hipStreamQuery of `stream` and of the engine's
+ * side stream, hipEventQuery of the two events that join them (0 = complete, 600 = not ready),
+ * without waiting for anything.  No counterpart in the reference. */
+int icap_engine_debug_sync_state(const icap_engine* engine, icap_stream_t stream, int32_t state[4]);
 /* The engine runs the vocab projection and the beam step fused (icap_dense_topk_f32 +
  * icap_beam_step_from_records_f32; in bf16 mode the bf16 projection writes the same
  * records) whenever its shape is served: for fp32 V % 4 == 0, H % 32 == 0 (beams wider than 5

@@ -215,3 +215,19 @@ def test_bahdanau_attention_layer_with_another_activation(activation):
     assert tuple(w.shape) == (N, L, 1)
     assert_close(np_of(w), w_ref, what="weights")
     assert_close(np_of(ctx), ctx_ref, what="context")
+
+
+def test_operand_devices_left_by_a_failed_call_do_not_leak_into_the_next():
+    """The operators note the device of every checked operand per call.  A call whose argument
+    list raises after a check never resolves its set; the next call (another frame) must drop
+    it instead of reporting operands on different devices."""
+    from image_caption_amd import ops
+    x = to_dev(np.ones((4, 8), np.float32))
+    k = to_dev(np.ones((8, 8), np.float32))
+    ops._pending().add(torch.device("cuda", 1))      # what an interrupted call on another GPU leaves
+    ops._tls.frame = object()
+    y = ops.dense(x, k)
+    torch.cuda.synchronize()
+    assert_close(np_of(y), np.full((4, 8), 8.0, np.float32), what="dense after a stale operand set")
+    t = ops.position_table(6, 8, dev())
+    assert t.device == dev() and not ops._pending()

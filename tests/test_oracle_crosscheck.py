@@ -366,3 +366,18 @@ def test_transformer_step_equals_full_prefix_recomputation():
     x_short = p["t_embedding"][hidden[0][:, :3]] + co.relative_position_embedding(3, dims["hidden"])[None]
     short = co.transformer_decoder_stack(p, x_short, feats, dims["n_layers"], dims["heads"], dims["key_dim"])
     np.testing.assert_allclose(short, full[:, :3], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("W", [1, 3])
+def test_torch_cpu_reference_equals_numpy_oracle(W):
+    """The torch-CPU op-for-op loop that the benchmark times as the CPU baseline decodes the
+    same tokens as the numpy oracle (reference tile order, peaked weights so that captions
+    differ and end tokens occur)."""
+    import torch
+    from oracle import torch_cpu_reference as tr
+    dims = dict(F=24, D=8, E=8, H=12, V=37)
+    p = co.perturb_biases(co.make_peaked_params(3, **dims), 4)
+    img = co.make_images(5, 6, 5, dims["F"])
+    ref = co.predict_image_caption_sequence(p, img, W, 7, 3, 4, 1.0, "reference")
+    got = tr.predict_image_caption_sequence(tr.to_torch(p), torch.from_numpy(img), W, 7, 3, 4, 1.0)
+    np.testing.assert_array_equal(got.numpy(), ref)

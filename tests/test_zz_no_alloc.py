@@ -71,8 +71,10 @@ def _run_both(lib, seed, B, W, V, time, eos, lpw):
 def test_static_workspace_beam_step_matches_caller_workspace_twice_in_a_row():
     from image_caption_amd import _lib
     lib = _lib.load()
-    # first a large call (every slot of the shared array it needs gets written) ...
-    _run_both(lib, 1, B=96, W=10, V=5000, time=3, eos=4, lpw=1.0)
+    # first a large call (every slot of the shared array it needs gets written); when this is
+    # the first call of the process it also looks the array's address up: no allocation either
+    before, after = _run_both(lib, 1, B=96, W=10, V=5000, time=3, eos=4, lpw=1.0)
+    assert after >= before, "the first call of the no-allocation entry point changed the free device memory"
     # ... then a smaller one right behind it on the same GPU: stale contents of the first
     # call must not leak into it
     before, after = _run_both(lib, 2, B=7, W=3, V=1003, time=2, eos=0, lpw=1.2)
@@ -94,3 +96,42 @@ def test_static_workspace_beam_step_rejects_sizes_beyond_its_array():
     # the largest size it takes: B*W == the limit (small vocabulary keeps the logits small)
     B = _lib.BEAM_STEP_STATIC_MAX_ROWS // 16
     _run_both(lib, 5, B=B, W=16, V=32, time=1, eos=4, lpw=1.0)
+
+
+def test_static_workspace_beam_step_inside_a_captured_graph():
+    """After one call outside capture (the address look-up), the entry point only enqueues: a
+    call captured into a graph replays with the results of the caller-workspace form, bit for
+    bit, also for new logits in the same buffers."""
+    from image_caption_amd import _lib
+    lib = _lib.load()
+    B, W, V, time, eos, lpw = 9, 4, 777, 2, 4, 1.0
+    _run_both(lib, 6, B=B, W=W, V=V, time=time, eos=eos, lpw=lpw)          # warm-up outside capture
+    cases = [_case(seed, B, W, V, time) for seed in (7, 8)]
+    d_logits, d_lp = to_dev(cases[0][0]).clone(), to_dev(cases[0][1]).clone()
+    d_fin, d_len = to_dev(cases[0][2].astype(np.uint8)).clone(), to_dev(cases[0][3]).clone()
+    got = _outputs(B, W)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        _lib.check(lib.icap_beam_step_static_f32(d_logits.data_ptr(), d_lp.data_ptr(), d_fin.data_ptr(),
+                                                 d_len.data_ptr(), time, 0, eos, lpw, 0,
+                                                 *[t.data_ptr() for t in got], B, W, V,
+                                                 torch.cuda.current_stream().cuda_stream))
+    need = int(lib.icap_beam_step_workspace_bytes(B, W))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+    for logits, lp, fin, lens in cases:
+        d_logits.copy_(to_dev(logits)); d_lp.copy_(to_dev(lp))
+        d_fin.copy_(to_dev(fin.astype(np.uint8))); d_len.copy_(to_dev(lens))
+        for t in got:
+            t.fill_(113)
+        g.replay()
+        torch.cuda.synchronize()
+        ref = _outputs(B, W)
+        _lib.check(lib.icap_beam_step_f32(d_logits.data_ptr(), d_lp.data_ptr(), d_fin.data_ptr(),
+                                          d_len.data_ptr(), time, 0, eos, lpw, 0,
+                                          *[t.data_ptr() for t in ref], B, W, V, ws.data_ptr(), need,
+                                          torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(np_of(a).view(np.uint8), np_of(b).view(np.uint8))
