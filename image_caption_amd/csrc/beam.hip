@@ -139,8 +139,12 @@ constexpr int LIST_CAP = 256;  // contenders a row can hand to wave 0 through LD
 //    division) and extracts the best WL in tf.nn.top_k order with DPP argmax rounds.
 // 3. if the list overflows (massive ties, or fewer than WL finite logits) every wave
 //    joins WL rounds of an exact workgroup-wide argmax instead.
-template <int NT, int ITEMS, int WL, bool VEC>
+// SOLO (WL == 1, one row per image, one successor: greedy decoding): the row's workgroup also
+// does what beam_merge_kernel would do for its image - the finished row's synthetic candidates,
+// the gathers and the next state - so the step is one launch.
+template <int NT, int ITEMS, int WL, bool VEC, bool SOLO = false>
 __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
+  static_assert(!SOLO || WL == 1, "the one-launch form serves one row and one successor per image");
   constexpr int NWV = NT / 64;
   constexpr bool CACHED = ITEMS > 0;
   constexpr int NX = CACHED ? ITEMS : 1;
@@ -179,7 +183,37 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) load_item<NT, VEC>(row, i, tid, V, xs[i]);
   }
-  if (p.finished[rw]) return;  // candidates of finished beams are made by the merge kernel
+  if (p.finished[rw]) {  // candidates of finished beams are made by the merge kernel
+    if constexpr (SOLO) {
+      if (tid == 0) {
+        // as there: log-prob 0 at eos and f32.min elsewhere, so only the first WL + 1 columns
+        // and the eos column can win (all other columns tie behind column 0)
+        const float lp0 = p.log_probs[rw];
+        const int len0 = p.lengths[rw];
+        const float pen = penalty_of(p.pen, len0);
+        const int ncol = min(V, 2);
+        float bs = -INFINITY, bt = 0.f;
+        int bi = EMPTY_IDX;
+        for (int j = 0; j <= ncol; ++j) {
+          int col = -1;
+          if (j < ncol) col = j;
+          else if (p.eos >= ncol && p.eos < V) col = p.eos;
+          if (col < 0) continue;
+          const float total = lp0 + ((col == p.eos) ? 0.f : kF32Min);
+          const float sc = total / pen;
+          if (cand_better(sc, col, bs, bi)) { bs = sc; bt = total; bi = col; }
+        }
+        const int word = (bi == EMPTY_IDX) ? 0 : bi;
+        p.scores[rw] = bs;
+        p.ids[rw] = word;
+        p.parents[rw] = 0;
+        p.next_lp[rw] = bt;
+        p.next_fin[rw] = 1;
+        p.next_len[rw] = len0;
+      }
+    }
+    return;
+  }
   if (tid == 0) l_n = 0;
   for (int q = NWV * WL + tid; q < 64 * PERB; q += NT) s_top[q] = -INFINITY;  // unused slots
 
@@ -381,6 +415,22 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(BeamArgs p) {
       if (tid == r) { my_s = bs; my_t = bt; my_i = bi; }
     }
     if (wave != 0) return;
+  }
+  if constexpr (SOLO) {
+    // (every thread of the workgroup loaded its state words before the barriers above, so
+    // the next state may be written over the state inputs)
+    if (lane == 0) {
+      const int flat = (my_i == EMPTY_IDX) ? 0 : my_i;
+      const int word = flat % V;
+      const int nfin = (word == p.eos) ? 1 : 0;
+      p.scores[rw] = my_s;
+      p.ids[rw] = word;
+      p.parents[rw] = flat / V;
+      p.next_lp[rw] = my_t;
+      p.next_fin[rw] = (uint8_t)nfin;
+      p.next_len[rw] = len + ((word != p.eos && !nfin) ? 1 : 0);
+    }
+    return;
   }
   if (lane < WL) {
     p.ws_score[rw * WL_MAX + lane] = my_s;
@@ -1066,8 +1116,18 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const int32_t* __restric
 }
 
 template <int NT, int ITEMS, int WL>
-int launch_row(const BeamArgs& a, bool vec, hipStream_t s) {
+int launch_row(const BeamArgs& a, bool vec, hipStream_t s, bool solo = false) {
   const dim3 grid(a.B * a.R), block(NT);
+  if constexpr (WL == 1) {
+    if (solo) {
+      if (vec)
+        hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, 1, true, true>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, 1, false, true>), grid, block, 0, s, a);
+      ICAP_LAUNCH_CHECK("beam_row_kernel<solo>");
+      return ICAP_OK;
+    }
+  }
   if (vec)
     hipLaunchKernelGGL((beam_row_kernel<NT, ITEMS, WL, true>), grid, block, 0, s, a);
   else
@@ -1080,6 +1140,19 @@ template <int WL>
 int dispatch_beam(const BeamArgs& a, bool vec, hipStream_t s) {
   int rc;
   const int V = a.V;
+  // greedy decoding (one row, one successor per image, no device-side switch): the row kernel
+  // finishes the step itself.  Tuning knob ICAP_BEAM_SOLO=0: two launches.
+  static const char* solo_env = getenv("ICAP_BEAM_SOLO");
+  const bool solo = WL == 1 && a.R == 1 && a.W == 1 && !a.run_flag && !a.clear_flag &&
+                    !(solo_env && solo_env[0] == '0');
+  if (solo) {
+    if (V <= 256 * 4 * 4) return launch_row<256, 4, WL>(a, vec, s, true);
+    if (V <= 256 * 4 * 10) return launch_row<256, 10, WL>(a, vec, s, true);
+    if (V <= 256 * 4 * 16) return launch_row<256, 16, WL>(a, vec, s, true);
+    if (V <= 1024 * 4 * 13) return launch_row<1024, 13, WL>(a, vec, s, true);
+    if (V <= 1024 * 4 * 16) return launch_row<1024, 16, WL>(a, vec, s, true);
+    return launch_row<1024, 0, WL>(a, vec, s, true);
+  }
   if (V <= 256 * 4 * 4) rc = launch_row<256, 4, WL>(a, vec, s);
   else if (V <= 256 * 4 * 10) rc = launch_row<256, 10, WL>(a, vec, s);
   else if (V <= 256 * 4 * 16) rc = launch_row<256, 16, WL>(a, vec, s);

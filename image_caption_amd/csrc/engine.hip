@@ -45,6 +45,9 @@ int lstm_step_bf16(const float*, const float*, const float*, const void*, const 
                    const int32_t*, float*, float*, int, int, int, int, hipStream_t);
 int gru_step_bf16(const float*, const float*, const void*, const float*, const float*, const int32_t*,
                   float*, int, int, int, int, hipStream_t);
+int cell_gates_bf16(const float*, const float*, const void*, float*, int, int, int, hipStream_t);
+int cell_update_f32(int, const float*, const float*, const float*, const int32_t*, const float*, float*,
+                    float*, int, int, int, hipStream_t);
 int dense_topk_half_tiles(int N);
 int dense_topk_record_floats(int top_k);
 bool dense_topk_supported(const float*, const float*, int, int, int, int);
@@ -263,6 +266,10 @@ struct icap_engine {
   int32_t* len2 = nullptr;
   long wide_rescues_forced = 0;  // test hook: raise the flag at every step
   bool a16 = true;               // bf16 mode: bf16 hand-over between fc1 and the projection (ICAP_BF16_A16=0: off)
+  // bf16 mode, side-stream schedule: the cell step as two launches (cell_gates_bf16 on the side
+  // stream behind the attention, cell_update_f32 on the caller's stream behind the beam step)
+  bool split_cell = false;
+  float* zgates = nullptr;       // [N][4H] gate pre-activations of the next step
   // fc1 and fc2 have no activation between them (decoder/lstm_recurrent_decoder.py:41-42,
   // 106-112; the dropout is the identity at inference), so logits = h . (W1 . W2) + (b1 . W2 + b2):
   // the product of the two kernels and the combined bias are formed once per engine (sums in
@@ -590,12 +597,28 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
                                     w.att_w2_kernel, w.att_w2_bias, e->ctx, c.B, c.W, stride_g,
                                     stride_k, c.L, c.U, c.D, c.H, att_blocks, s);
   };
+  // bf16 mode on the side-stream schedule: the gate product [ctx | h] . W of step t+1 needs the
+  // attention of step t+1 and h of step t, not the token the beam step of step t picks - only
+  // the token's gate rows and the cell update do.  So the product runs on the side stream
+  // behind the attention (cell_gates_bf16) and what is left on the critical path behind the
+  // beam step is a pointwise kernel (cell_update_f32; the same bits as the one-launch step):
+  //   main: cell_t -> fc1_t -> vocab_t -> beam_t -> cell_{t+1} ...
+  //   side:     \-> query_{t+1} -> attention_{t+1} -> gates_{t+1} -/
+  const bool split_cell = e->split_cell && side && bf16;
   int cur = 0;
   ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
+  if (split_cell) {
+    Timed tm(e, ICAP_K_LSTM, s);
+    ICAP_TRY(cell_gates_bf16(e->ctx, e->h[cur], e->pk[icap_engine::PK_LSTM], e->zgates, N, c.D, c.H, s));
+  }
   for (int t = 0; t < c.T; ++t) {
     const int32_t* ids = t == 0 ? e->start_ids : e->hist_ids + (size_t)(t - 1) * N;
     if (t > 0 && side) ICAP_HIP(hipStreamWaitEvent(s, e->ev_att, 0));
-    {  // K6: LSTM cell on [ctx | emb(ids) | h]
+    if (split_cell) {
+      Timed tm(e, ICAP_K_LSTM, s);
+      ICAP_TRY(cell_update_f32(gru ? 1 : 0, e->zgates, e->cell_bias, e->emb_proj, ids,
+                               gru ? e->h[cur] : e->c, e->h[cur ^ 1], gru ? nullptr : e->c, N, c.H, c.V, s));
+    } else {  // K6: LSTM cell on [ctx | emb(ids) | h]
       Timed tm(e, ICAP_K_LSTM, s);
       if (gru && c.precision == ICAP_PRECISION_BF16)
         ICAP_TRY(gru_step_bf16(e->ctx, e->h[cur], e->pk[icap_engine::PK_LSTM], e->cell_bias,
@@ -621,6 +644,11 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_HIP(hipEventRecord(e->ev_lstm, s));
       ICAP_HIP(hipStreamWaitEvent(e->side, e->ev_lstm, 0));
       ICAP_TRY(attention_step(e->side, gru ? e->h[cur] : e->c));
+      if (split_cell) {
+        Timed tm(e, ICAP_K_LSTM, e->side);
+        ICAP_TRY(cell_gates_bf16(e->ctx, e->h[cur], e->pk[icap_engine::PK_LSTM], e->zgates, N, c.D,
+                                 c.H, e->side));
+      }
       ICAP_HIP(hipEventRecord(e->ev_att, e->side));
     }
     const float* lp_in = t == 0 ? e->lp : e->hist_lp + (size_t)(t - 1) * N;
@@ -1100,6 +1128,14 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   const size_t o_epf = cv.take<float>(att_table ? BL * c.U : 0), o_ext = cv.take<int>(64);
   const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
       cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
+  // (ICAP_BF16_SPLIT_CELL=1, read per engine: the cell step of the bf16 side-stream schedule as
+  // gate product + cell update, see decode_impl.  Opt-in: measured 179k against 189k captions/s
+  // at B = 512, beam 5 and 221k against 233k at beam 3 - the gate product lengthens the side
+  // chain (query, attention, product) to the length of the main one and competes with the
+  // projection's tail and the beam step for the L2.)
+  const char* sc_env = getenv("ICAP_BF16_SPLIT_CELL");
+  const bool split_cell = c.precision == ICAP_PRECISION_BF16 && sc_env && sc_env[0] == '1';
+  const size_t o_zg = cv.take<float>(split_cell ? N * 4 * c.H : 0);
   const bool gru = c.cell == ICAP_CELL_GRU;
   const size_t o_gk = cv.take<float>(gru ? (size_t)(c.D + c.E) * 4 * c.H : 0),
                o_gr = cv.take<float>(gru ? (size_t)c.H * 4 * c.H : 0),
@@ -1281,6 +1317,8 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
         dense_topk_beam_supported((int)N, c.W, dense_topk_half_tiles(c.V), e->topk_able, 1, 0);
   }
   e->fc1o16 = (uint16_t*)(b + o_fc116);
+  e->split_cell = split_cell;
+  if (split_cell) e->zgates = (float*)(b + o_zg);
   {
     const char* a16_env = getenv("ICAP_BF16_A16");  // tuning knob, read per engine
     e->a16 = !(a16_env && a16_env[0] == '0');

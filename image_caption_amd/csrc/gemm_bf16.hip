@@ -97,7 +97,13 @@ constexpr int gemm_bf16_smem_bytes() {
 // One tile by a 256-thread workgroup; bid = position in the tile grid, smem = the workgroup's
 // LDS (gemm_bf16_smem_bytes).  COH: the plain epilogue stores y with device scope, for a
 // reader inside the same launch (the query tiles of vocab_bf16_attq_kernel).
-template <int BM, bool LSTM, int TOPK = 0, bool A16 = false, bool COH = false>
+// PAIR: two K stages per trip of the loop, the loads of both in flight over the multiplies of
+// two stages (the two LDS buffers then hold the pair being multiplied, so a second barrier per
+// trip separates their last read from the stores of the next pair; K / 64 must be even).  An
+// experiment that answered a question: a trip of the plain loop takes about a microsecond,
+// as long as a load from a busy L2 - but halving the number of exposed latencies does not
+// shorten the loop, so the loop is bound by operand throughput, not by latency.
+template <int BM, bool LSTM, int TOPK = 0, bool A16 = false, bool COH = false, bool PAIR = false>
 __device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid, char* const smem) {
   constexpr int NT = 256;
   constexpr int WTM = BM / 2;    // wave tile rows
@@ -158,37 +164,46 @@ __device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid,
     a_row[i] = A16 ? min(m0 + b_r + 32 * i, p.M - 1) : min(m0 + a_r + 16 * i, p.M - 1);
   float4 ra[A_LD];  // (A16: the same 16 bytes hold 8 bf16)
   uint4 rb[B_LD];
+  float4 ra2[PAIR ? A_LD : 1];  // PAIR: the second stage of the pair in flight
+  uint4 rb2[PAIR ? B_LD : 1];
   // (macros, not lambdas: arrays captured by a lambda are not split into registers)
-#define ICAP_BF16_LOAD(KT)                                                                         \
+#define ICAP_BF16_LOAD_INTO(RA, RB, KT)                                                            \
   {                                                                                                \
     const int k0_ = (KT) * BK;                                                                     \
     const bool seg0_ = k0_ < p.K0; /* uniform over the workgroup */                                \
     const float* base_ = seg0_ ? p.a0 : p.a1;                                                      \
     const int ld_ = seg0_ ? p.lda0 : p.lda1;                                                       \
     const int kk_ = (seg0_ ? k0_ : k0_ - p.K0) + a_c4 * 4;                                         \
-    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) ra[i] = A16                                   \
+    _Pragma("unroll") for (int i = 0; i < A_LD; ++i) RA[i] = A16                                   \
         ? *reinterpret_cast<const float4*>(p.a16 + (size_t)a_row[i] * p.lda16 + k0_ + b_ch * 8)    \
         : *reinterpret_cast<const float4*>(base_ + (size_t)a_row[i] * ld_ + kk_);                  \
-    _Pragma("unroll") for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const uint4*>(      \
+    _Pragma("unroll") for (int j = 0; j < B_LD; ++j) RB[j] = *reinterpret_cast<const uint4*>(      \
         p.w + (size_t)(n0 + b_r + 32 * j) * p.K + k0_ + b_ch * 8);                                 \
   }
-#define ICAP_BF16_STORE(BUF)                                                                       \
+#define ICAP_BF16_STORE_FROM(RA, RB, BUF)                                                          \
   {                                                                                                \
     char* as_ = smem + (BUF) * STAGE;                                                              \
     char* bs_ = as_ + A_BYTES;                                                                     \
     _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                             \
       if (A16) {                                                                                   \
-        *reinterpret_cast<float4*>(as_ + (b_r + 32 * i) * ROW_B + b_sw) = ra[i];                   \
+        *reinterpret_cast<float4*>(as_ + (b_r + 32 * i) * ROW_B + b_sw) = RA[i];                   \
       } else {                                                                                     \
         bf16x4 v_;                                                                                 \
-        v_[0] = (__bf16)ra[i].x; v_[1] = (__bf16)ra[i].y;                                          \
-        v_[2] = (__bf16)ra[i].z; v_[3] = (__bf16)ra[i].w;                                          \
+        v_[0] = (__bf16)RA[i].x; v_[1] = (__bf16)RA[i].y;                                          \
+        v_[2] = (__bf16)RA[i].z; v_[3] = (__bf16)RA[i].w;                                          \
         *reinterpret_cast<bf16x4*>(as_ + (a_r + 16 * i) * ROW_B + a_sw) = v_;                      \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                               \
-        *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_sw) = rb[j];                    \
+        *reinterpret_cast<uint4*>(bs_ + (b_r + 32 * j) * ROW_B + b_sw) = RB[j];                    \
   }
+#define ICAP_BF16_LOAD(KT) ICAP_BF16_LOAD_INTO(ra, rb, KT)
+#define ICAP_BF16_STORE(BUF) ICAP_BF16_STORE_FROM(ra, rb, BUF)
+#define ICAP_BF16_PIN(RA, RB)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < A_LD; ++i)                                                 \
+      asm volatile("" : "+v"(RA[i].x), "+v"(RA[i].y), "+v"(RA[i].z), "+v"(RA[i].w));               \
+  _Pragma("unroll") for (int j = 0; j < B_LD; ++j)                                                 \
+      asm volatile("" : "+v"(RB[j].x), "+v"(RB[j].y), "+v"(RB[j].z), "+v"(RB[j].w));
 
   // LSTM / GRU epilogue operands of this thread's (row, unit) pairs - the token-only gate
   // pre-activations (a gather by id) and the previous state - are fetched here, ahead of the
@@ -236,16 +251,9 @@ __device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid,
   // multiplies; the staging registers then pass through an empty asm so that their first
   // use (a register-only conversion) and its wait stay below the multiplies.
   const int nk = p.K / BK;
-  ICAP_BF16_LOAD(0)
-  ICAP_BF16_STORE(0)
-  if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
-  ICAP_STAMP(1)
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    ICAP_BF16_LOAD(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch
-    __syncthreads();
-    const char* as = smem + cur * STAGE + (wm * WTM + l31) * ROW_B;
-    const char* bs = smem + cur * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B;
+  auto multiply_stage = [&](int buf) {
+    const char* as = smem + buf * STAGE + (wm * WTM + l31) * ROW_B;
+    const char* bs = smem + buf * STAGE + A_BYTES + (wn * 64 + l31) * ROW_B;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[TM], b[TN];
@@ -259,18 +267,50 @@ __device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid,
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) asm volatile("" : "+v"(rb[j].x), "+v"(rb[j].y), "+v"(rb[j].z), "+v"(rb[j].w));
-    ICAP_BF16_STORE(cur ^ 1)
-    cur ^= 1;
+  };
+  if constexpr (PAIR) {
+    ICAP_BF16_LOAD_INTO(ra, rb, 0)
+    ICAP_BF16_LOAD_INTO(ra2, rb2, 1)
+    ICAP_BF16_STORE_FROM(ra, rb, 0)
+    ICAP_BF16_STORE_FROM(ra2, rb2, 1)
+    if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
+    ICAP_STAMP(1)
+    for (int kt = 0; kt < nk; kt += 2) {
+      // (the last trip re-loads its own pair: no branch around the loads)
+      ICAP_BF16_LOAD_INTO(ra, rb, min(kt + 2, nk - 2))
+      ICAP_BF16_LOAD_INTO(ra2, rb2, min(kt + 3, nk - 1))
+      __syncthreads();  // the pair (kt, kt + 1) is in LDS
+      multiply_stage(0);
+      multiply_stage(1);
+      ICAP_BF16_PIN(ra, rb)
+      ICAP_BF16_PIN(ra2, rb2)
+      __syncthreads();  // nobody reads the pair any more
+      ICAP_BF16_STORE_FROM(ra, rb, 0)
+      ICAP_BF16_STORE_FROM(ra2, rb2, 1)
+    }
+  } else {
+    ICAP_BF16_LOAD(0)
+    ICAP_BF16_STORE(0)
+    if constexpr (LSTM && HOIST) ICAP_BF16_CELL_OPERANDS
+    ICAP_STAMP(1)
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      ICAP_BF16_LOAD(min(kt + 1, nk - 1))  // the last one is a harmless repeat: no branch
+      __syncthreads();
+      multiply_stage(cur);
+      ICAP_BF16_PIN(ra, rb)
+      ICAP_BF16_STORE(cur ^ 1)
+      cur ^= 1;
+    }
   }
   __syncthreads();  // the epilogues reuse the LDS
   ICAP_STAMP(2)
 
 #undef ICAP_BF16_LOAD
 #undef ICAP_BF16_STORE
+#undef ICAP_BF16_LOAD_INTO
+#undef ICAP_BF16_STORE_FROM
+#undef ICAP_BF16_PIN
 
   if constexpr (TOPK > 0) {
     // The logits never reach memory: every wave writes its 64 x 64 patch (+ bias, -inf
@@ -383,10 +423,10 @@ __device__ __forceinline__ void gemm_bf16_body(const Bf16Args& p, const int bid,
   ICAP_STAMP(3)
 }
 
-template <int BM, bool LSTM, int TOPK = 0, bool A16 = false>
+template <int BM, bool LSTM, int TOPK = 0, bool A16 = false, bool PAIR = false>
 __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void gemm_bf16_kernel(Bf16Args p) {
   __shared__ __attribute__((aligned(16))) char smem[gemm_bf16_smem_bytes<BM, LSTM, TOPK>()];
-  gemm_bf16_body<BM, LSTM, TOPK, A16>(p, blockIdx.x, smem);
+  gemm_bf16_body<BM, LSTM, TOPK, A16, false, PAIR>(p, blockIdx.x, smem);
 }
 
 // The record projection on bf16 activations carrying the NEXT decode step's query projection
@@ -625,9 +665,21 @@ int dense_topk_bf16_a16(const void* x16, int blocked, const void* packed_w, cons
     a.stagger_wgs = 512;  // two workgroups on each of 256 compute units
   }
   const dim3 grid(a.tiles_m * a.tiles_n), block(256);
-  if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1, true>), grid, block, 0, s, a);
-  else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5, true>), grid, block, 0, s, a);
+  // Two K stages per loop trip (ICAP_BF16_PAIR=1, opt-in): measured no gain - the K loop of a
+  // tile takes 7.3-7.6 us either way (device timelines), i.e. it runs at the rate the operands
+  // arrive (256 KB per tile, 512 tiles at a time: 18 TB/s out of the L2s), not at the latency
+  // of a stage; 188k against 192k captions/s at B = 512, beam 5.
+  static const char* pair_env = getenv("ICAP_BF16_PAIR");
+  const bool pair = (K / BK) % 2 == 0 && pair_env && pair_env[0] == '1';
+  if (pair) {
+    if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1, true, true>), grid, block, 0, s, a);
+    else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5, true, true>), grid, block, 0, s, a);
+  } else {
+    if (top_k == 1) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 1, true>), grid, block, 0, s, a);
+    else if (top_k == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 3, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, false, 5, true>), grid, block, 0, s, a);
+  }
   ICAP_LAUNCH_CHECK("gemm_bf16_kernel<topk,a16>");
   return ICAP_OK;
 }
@@ -731,6 +783,77 @@ int gru_step_bf16(const float* ctx, const float* h, const void* packed_w, const 
                   hipStream_t s) {
   return cell_step_bf16(1, ctx, h, nullptr, packed_w, bias4, emb_proj, ids, h_out, nullptr, N, C, H, V,
                         s);
+}
+
+// The cell step in two launches, for a schedule that wants the gate product off its critical
+// path: the product [ctx | h] . W does not depend on the token the beam step is about to pick,
+// only the token's gate rows emb_proj[id] and the cell update do.
+//   cell_gates_bf16   z[N][4H] = [ctx | h] . W   (columns in the packed, gate-interleaved order:
+//                     column (u / 32) * 128 + g * 32 + u % 32 is gate g of unit u; no bias)
+//   cell_update_f32   (z + bias) + emb_proj[id], then the LSTM / GRU update of cell_step_bf16's
+//                     epilogue, operation for operation: the two launches give the bits of the one.
+int cell_gates_bf16(const float* ctx, const float* h, const void* packed_w, float* z, int N, int C,
+                    int H, hipStream_t s) {
+  ICAP_REQUIRE(ctx && h && packed_w && z, "cell_gates_bf16: null pointer");
+  ICAP_REQUIRE(N > 0 && C > 0 && H > 0 && C % BK == 0 && H % BK == 0,
+               "cell_gates_bf16: C=%d and H=%d must be positive multiples of %d", C, H, BK);
+  ICAP_REQUIRE(aligned16(ctx) && aligned16(h) && aligned16(packed_w),
+               "cell_gates_bf16: operands must be 16-byte aligned");
+  Bf16Args a = {};
+  a.a0 = ctx; a.a1 = h; a.K0 = C; a.lda0 = C; a.lda1 = H;
+  a.w = static_cast<const uint16_t*>(packed_w);
+  a.bias = nullptr; a.y = z; a.M = N; a.N = 4 * H; a.K = C + H; a.act = ICAP_ACT_NONE;
+  const long long tiles64 = (long long)ceil_div(N, 64) * ceil_div(4 * H, BN);
+  if (tiles64 > 768) return launch<128, false>(a, s, "gemm_bf16_kernel<gates,128>");
+  return launch<64, false>(a, s, "gemm_bf16_kernel<gates>");
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cell_update_kernel(const float* __restrict__ z,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ emb_proj,
+                                                          const int32_t* __restrict__ ids,
+                                                          const float* __restrict__ state_in,
+                                                          float* __restrict__ h_out,
+                                                          float* __restrict__ c_out, int N, int H, int V,
+                                                          int gru) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * H) return;
+  const int m = (int)(idx / H), unit = (int)(idx - (long long)m * H);
+  const float* zrow = z + (size_t)m * 4 * H + (unit >> 5) * 128 + (unit & 31);
+  const int id = emb_proj ? min(max(ids[m], 0), V - 1) : 0;
+  const float* ep = emb_proj ? emb_proj + (size_t)id * 4 * H + unit : nullptr;
+  float zz[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    zz[g] = (zrow[g * 32] + (bias ? bias[g * H + unit] : 0.f)) + (ep ? ep[g * H] : 0.f);
+  const float st = state_in[idx];
+  if (gru) {
+    const float zg = fast_sigmoid(zz[0]), rg = fast_sigmoid(zz[1]);
+    const float hh = fast_tanh(zz[2] + rg * zz[3]);
+    h_out[idx] = zg * st + (1.f - zg) * hh;
+  } else {
+    const float cn = fast_sigmoid(zz[1]) * st + fast_sigmoid(zz[0]) * fast_tanh(zz[2]);
+    c_out[idx] = cn;
+    h_out[idx] = fast_sigmoid(zz[3]) * fast_tanh(cn);
+  }
+}
+}  // namespace
+
+// state_in: the previous cell state c (LSTM; c_out may alias it) or the previous h (GRU, c_out null)
+int cell_update_f32(int gru, const float* z, const float* bias, const float* emb_proj,
+                    const int32_t* ids, const float* state_in, float* h_out, float* c_out, int N,
+                    int H, int V, hipStream_t s) {
+  ICAP_REQUIRE(z && state_in && h_out && (gru || c_out), "cell_update_f32: null pointer");
+  ICAP_REQUIRE(N > 0 && H > 0 && H % 32 == 0, "cell_update_f32: H=%d must be a positive multiple of 32", H);
+  ICAP_REQUIRE((emb_proj == nullptr) == (ids == nullptr), "cell_update_f32: emb_proj and ids come together");
+  ICAP_REQUIRE(!emb_proj || V > 0, "cell_update_f32: vocabulary size missing");
+  ICAP_REQUIRE(!gru || h_out != state_in, "cell_update_f32: h_out must not alias the previous h");
+  const long long total = (long long)N * H;
+  hipLaunchKernelGGL(cell_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, bias,
+                     emb_proj, ids, state_in, h_out, c_out, N, H, V, gru);
+  ICAP_LAUNCH_CHECK("cell_update_kernel");
+  return ICAP_OK;
 }
 
 namespace {

@@ -251,9 +251,12 @@ struct FastLds {
 // The work of workgroup `block` of the grid (a kernel may give its first workgroups other
 // work and pass the rest on with their index shifted down).
 // Returns the tile row it worked on.  COH: the records are stored device-coherently.
-template <int BM, int BN, int WM, int WN, int TOPK, bool COH = false>
+// BMG / sub: the grid of tiles is BMG rows high and this workgroup takes rows
+// [sub * BM, (sub + 1) * BM) of its tile (BMG == BM, sub == 0: the whole tile).
+template <int BM, int BN, int WM, int WN, int TOPK, bool COH = false, int BMG = BM>
 __device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
-                                               typename FastLds<BM, BN, WM, WN, TOPK>::U& lds) {
+                                               typename FastLds<BM, BN, WM, WN, TOPK>::U& lds,
+                                               int sub = 0) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -270,7 +273,7 @@ __device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
   int tile_m, tile_n;
   if (p.band_order) tile_of_block_band(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
   else tile_of_block(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
-  const int m0 = tile_m * BM;
+  const int m0 = tile_m * BMG + sub * BM;
   const int n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
@@ -517,11 +520,20 @@ __global__ __launch_bounds__(512, 4)  // (min 4 waves per SIMD: two workgroups p
 // for a slot held by a waiting attention workgroup; should a wait run out all the same
 // (2^16 polls, a fraction of a second) the workgroup raises *err and leaves its rows
 // untouched - the caller turns that into an invalid result rather than a wrong one.
+//
+// The tail: the launch ends when its last workgroups do, and a 128 x 128 tile that starts late
+// holds its compute unit for 40 to 55 us.  The vocab tiles from number split_from on (the last
+// ones in grid order, a multiple of 8 of them) are therefore cut into two workgroups of
+// 64 x 128 each (four of the eight waves work, the others leave at once; the two halves sit 8
+// apart in the grid, on the same XCD, where they share the tile's weight panel in L2), which
+// halves the granularity of what is still running at the end.
 template <int TOPK, int RB>
 __global__ __launch_bounds__(512, 4)
     void dense_topk_attq_kernel(DenseArgs p, DenseArgs pq, AttArgs a, int nq, int att_blocks,
-                                int tiles_before, unsigned* q_done, unsigned q_target, int* err) {
+                                int tiles_before, int split_from, unsigned* q_done, unsigned q_target,
+                                int* err) {
   __shared__ typename FastLds<128, 128, 4, 2, TOPK>::U lds;
+  static_assert(sizeof(typename FastLds<64, 128, 2, 2, TOPK>::U) <= sizeof(lds), "the half tile's LDS lives in the tile's");
   static_assert(sizeof(typename FastLds<64, 128, 2, 4, 0>::U) <= sizeof(lds), "the query tile's LDS lives in the vocab tile's");
   // (both leading sections are padded to multiples of 8 workgroups so that the vocab tiles
   // keep their XCD; the padding workgroups return at once)
@@ -537,7 +549,15 @@ __global__ __launch_bounds__(512, 4)
   }
   ICAP_STAMP_F32(0)
   if (tile_id >= 0) {
-    dense_fast_body<128, 128, 4, 2, TOPK>(p, tile_id, lds);
+    if (tile_id < split_from) {
+      dense_fast_body<128, 128, 4, 2, TOPK>(p, tile_id, lds);
+    } else {
+      if (threadIdx.x >= 256) return;  // (a half tile is the work of four waves)
+      const int idx = tile_id - split_from;
+      dense_fast_body<64, 128, 2, 2, TOPK, false, 128>(
+          p, split_from + ((idx >> 4) << 3) + (idx & 7),
+          *reinterpret_cast<typename FastLds<64, 128, 2, 2, TOPK>::U*>(&lds), (idx >> 3) & 1);
+    }
     ICAP_STAMP_F32(1)
     return;
   }
@@ -1815,7 +1835,6 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
             G, R, stride_g, stride_k, L, U, D, H, att_blocks, nullptr, nullptr, nullptr};
   t.epf = epf;
   t.pf_extreme = pf_extreme;
-  const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + a.tiles_m * a.tiles_n), block(512);
   // Where the attention workgroups sit in the grid.  In front of every tile they hold one of
   // each compute unit's two slots from the start and the launch ends on a partly filled round
   // of tile pairs; behind one full round of tiles plus half of the slots that round frees,
@@ -1828,7 +1847,16 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
   tiles_before &= ~7;
   if (tiles_before < 0) tiles_before = 0;
   if (tiles_before > a.tiles_m * a.tiles_n) tiles_before = (a.tiles_m * a.tiles_n) & ~7;
-#define ICAP_ATTQ(TK, RB_) hipLaunchKernelGGL((dense_topk_attq_kernel<TK, RB_>), grid, block, 0, s, a, aq, t, nq, att_blocks, tiles_before, q_done, q_target, err)
+  // the tiles of the tail that are cut in two (see the kernel).  Tuning knob ICAP_TAIL_SPLIT.
+  static const char* ts_env = getenv("ICAP_TAIL_SPLIT");
+  const int n_tiles = a.tiles_m * a.tiles_n;
+  int split = ts_env ? atoi(ts_env) : 0;
+  split &= ~7;
+  if (split < 0) split = 0;
+  if (split > n_tiles - tiles_before) split = (n_tiles - tiles_before) & ~7;
+  const int split_from = n_tiles - split;
+  const dim3 grid(((nq + 7) & ~7) + ((att_blocks + 7) & ~7) + n_tiles + split), block(512);
+#define ICAP_ATTQ(TK, RB_) hipLaunchKernelGGL((dense_topk_attq_kernel<TK, RB_>), grid, block, 0, s, a, aq, t, nq, att_blocks, tiles_before, split_from, q_done, q_target, err)
   switch (R <= 5 ? R : 10 + attq_rows_per_pass(R)) {
     case 1: ICAP_ATTQ(1, 1); break;
     case 2: ICAP_ATTQ(3, 2); break;

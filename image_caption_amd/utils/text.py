@@ -86,3 +86,75 @@ def corpus_mean_bleu(reference_rows, hypothesis_rows, index_word):
         result = detokenize(hyp_ids, index_word)
         scores.append(sentence_bleu([real], result))
     return sum(scores) / len(scores) if scores else 0.0
+
+
+# ---- the tokenizer of the data pipeline (data/data_util.py:56-72) ---------------------------
+
+KERAS_FILTERS = '!"#$%&()*+.,-/:;=?@[\\]^_`{|}~'   # the reference's filter string (no '<', no '>')
+
+
+class Tokenizer:
+    """The id <-> word table that `fit_tokenizer` builds with `tf.keras.preprocessing.text.
+    Tokenizer(num_words=top_k, oov_token="<unk>", filters=...)`, restated from the published
+    behaviour of that class (TensorFlow is not installed here, so the table is checked against
+    the class's documented rules, not against its output):
+    texts are lower-cased, every filter character becomes a space, words are split on
+    whitespace; words are ranked by count, descending, ties in order of first appearance; the
+    out-of-vocabulary token takes index 1 and the ranked words follow from 2; `num_words` does
+    not shrink the table, it only maps ids >= num_words to the oov id in `texts_to_sequences`;
+    the reference then adds '<pad>' as id 0 (`data/data_util.py:64-65`).  With the reference's
+    filter string the caption markers '<s>' and '</s>' come out as the words '<s>' and
+    ('<', 's>'), which is why its end token is spelled 's>'."""
+
+    def __init__(self, num_words=None, oov_token="<unk>", filters=KERAS_FILTERS, lower=True):
+        self.num_words, self.oov_token, self.filters, self.lower = num_words, oov_token, filters, lower
+        self.word_counts = {}
+        self.word_index = {}
+        self.index_word = {}
+
+    def _words(self, text):
+        if self.lower:
+            text = text.lower()
+        return text.translate({ord(c): " " for c in self.filters}).split()
+
+    def fit_on_texts(self, texts):
+        for t in texts:
+            for w in self._words(t):
+                self.word_counts[w] = self.word_counts.get(w, 0) + 1
+        ranked = sorted(self.word_counts.items(), key=lambda kv: kv[1], reverse=True)   # stable
+        vocab = ([self.oov_token] if self.oov_token is not None else []) + [w for w, _ in ranked]
+        self.word_index = {w: i + 1 for i, w in enumerate(vocab)}
+        self.index_word = {i: w for w, i in self.word_index.items()}
+
+    def texts_to_sequences(self, texts):
+        oov = self.word_index.get(self.oov_token)
+        out = []
+        for t in texts:
+            seq = []
+            for w in self._words(t):
+                i = self.word_index.get(w)
+                if i is not None and (self.num_words is None or i < self.num_words):
+                    seq.append(i)
+                elif oov is not None:
+                    seq.append(oov)
+            out.append(seq)
+        return out
+
+
+def fit_tokenizer(captions, top_k):
+    """`fit_tokenizer(captions, top_k=...)`, data/data_util.py:56-66."""
+    tok = Tokenizer(num_words=top_k)
+    tok.fit_on_texts(captions)
+    tok.word_index["<pad>"] = 0
+    tok.index_word[0] = "<pad>"
+    return tok
+
+
+def pad_sequences_post(seqs, value=0):
+    """`pad_sequences(seqs, padding='post')` (data/data_util.py:70-71): int32 [n, longest]."""
+    import numpy as np
+    width = max((len(s) for s in seqs), default=0)
+    out = np.full((len(seqs), width), value, np.int32)
+    for r, s in enumerate(seqs):
+        out[r, :len(s)] = s
+    return out

@@ -116,6 +116,25 @@ def test_beam_step_random(bs, B, W, V, t, lpw):
     _check_step(bs, logits, state, t, W, V, eos, lpw)
 
 
+@pytest.mark.parametrize("V", [5, 37, 1000, 10000, 10001, 50000, 70000])
+@pytest.mark.parametrize("t", [0, 3])
+def test_beam_step_greedy_in_one_launch(bs, V, t):
+    """Beam width 1 with one row per image takes the row kernel that also finishes the step
+    (finished rows, gathers, next state): against the oracle for every row-length form of the
+    kernel, with finished rows, eos at the first / last column and a tie on the maximum."""
+    rng = np.random.default_rng(V + t)
+    B = 24
+    logits = rng.standard_normal((B, 1, V)).astype(np.float32) * 2
+    logits[3, 0, V - 1] = logits[3, 0, 1] = logits[3, 0].max() + 1.0    # a tie: the lower column wins
+    state = _random_state(rng, B, 1, t)
+    for eos in (0, V - 1, int(rng.integers(0, V))):
+        out_o, st_o, _, _ = _check_step(bs, logits, state, t, 1, V, eos, 1.0)
+        if t > 0:
+            assert state.finished.any() and not state.finished.all()
+        if eos not in (1, V - 1):       # (the eos column is scored with its own length penalty)
+            assert out_o.predicted_ids[3, 0] == (eos if state.finished[3, 0] else 1)
+
+
 def test_beam_step_exact_ties_prefer_lower_flat_index(bs):
     """Identical rows and quantised logits give bit-identical scores on both sides;
     tf.nn.top_k order (lower flat index first) must be reproduced."""

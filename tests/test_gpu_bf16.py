@@ -211,3 +211,52 @@ def test_engine_bf16_merged_launch_agrees_with_side_stream(monkeypatch, W):
     np.testing.assert_array_equal(tr0["ids"], tr1["ids"])
     np.testing.assert_array_equal(tr0["parents"], tr1["parents"])
     np.testing.assert_array_equal(b0, b1)
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("W", [1, 5])
+def test_engine_bf16_split_cell_step_gives_the_bits_of_the_fused_one(monkeypatch, cell, W):
+    """On the side-stream schedule the bf16 engine runs the cell step as two launches - the gate
+    product on the side stream behind the attention, the pointwise update behind the beam step
+    (ICAP_BF16_SPLIT_CELL=1, opt-in) - with the operations of the one-launch step in the same
+    order: tokens, every beam record, log-probs and scores are bit-identical."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    L, F, D, E, H, V = 16, 128, 64, 64, 256, 3000
+    p = co.perturb_biases(co.make_params(11, F, D, E, H, V), 12)
+    if cell == "gru":
+        p = co.add_gru_params(p, 13)
+    img = to_dev(co.make_images(14, 40, L, F))
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("ICAP_BF16_SPLIT_CELL", split)
+        cfg = CaptionConfig(B=40, W=W, L=L, F=F, D=D, E=E, H=H, U=H, V=V, T=8, start_id=3, eos_id=4,
+                            precision="bf16", cell=cell)
+        eng = CaptionEngine(cfg, {k: to_dev(v) for k, v in p.items()})
+        prefer_fused(eng)
+        assert not eng.merged_launch
+        tok, best = eng.decode(img)
+        tr = {k: np_of(v) for k, v in eng.trace().items()}
+        outs.append((np_of(tok), np_of(best), tr))
+        eng.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    for k in ("ids", "parents"):
+        np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k])
+    for k in ("scores", "log_probs"):
+        np.testing.assert_array_equal(outs[0][2][k].view(np.uint32), outs[1][2][k].view(np.uint32))
+
+
+def test_engine_bf16_paired_k_stages_give_the_same_bits(monkeypatch):
+    """ICAP_BF16_PAIR=1 (two K stages per trip of the record projection's loop, opt-in) sums the
+    stages in the same order: tokens, records and scores are bit-identical."""
+    dims = (16, 128, 64, 64, 256, 3000)
+    monkeypatch.setenv("ICAP_FUSED_TOPK", "1")
+    monkeypatch.setenv("ICAP_BF16_PAIR", "0")
+    _, _, t0, b0, tr0 = _decode_pair(40, 5, 8, dims, 7, "bf16", want_merged=False)
+    monkeypatch.setenv("ICAP_BF16_PAIR", "1")
+    _, _, t1, b1, tr1 = _decode_pair(40, 5, 8, dims, 7, "bf16", want_merged=False)
+    np.testing.assert_array_equal(t0, t1)
+    np.testing.assert_array_equal(b0.view(np.uint32), b1.view(np.uint32))
+    for k in ("ids", "parents"):
+        np.testing.assert_array_equal(tr0[k], tr1[k])
+    np.testing.assert_array_equal(tr0["scores"].view(np.uint32), tr1["scores"].view(np.uint32))

@@ -44,3 +44,21 @@ def test_detokenize_drops_control_tokens():
     ref = [[3, 5, 6, 7, 5, 6, 4, 0]]
     assert corpus_mean_bleu(ref, ref, index_word) == pytest.approx(1.0)
     assert corpus_mean_bleu([], [], index_word) == 0.0
+
+
+def test_tokenizer_table_follows_the_keras_rules():
+    """fit_tokenizer (data/data_util.py:56-66): ids by descending count with ties in order of
+    appearance, '<unk>' = 1, '<pad>' = 0, the markers '<s>' / '</s>' become '<s>' and '<', 's>'
+    under the reference's filter string, ids >= top_k map to '<unk>'.  Parity unpinned
+    (TensorFlow absent): checked against the documented behaviour of the Keras class."""
+    from image_caption_amd.utils.text import fit_tokenizer, pad_sequences_post
+    caps = ["<s> A dog runs. </s>", "<s> a DOG sits, a cat sleeps </s>", "<s> a bird </s>"]
+    tok = fit_tokenizer(caps, top_k=8)
+    assert tok.index_word[0] == "<pad>" and tok.index_word[1] == "<unk>"
+    # counts: a 4; <s>, <, s> 3 each (that order of appearance); dog 2; then runs, sits, cat, ...
+    assert [tok.index_word[i] for i in range(2, 10)] == ["a", "<s>", "<", "s>", "dog", "runs", "sits", "cat"]
+    assert tok.word_index["s>"] == 5 and tok.word_index["<s>"] == 3
+    seqs = tok.texts_to_sequences(["<s> a cat runs </s>", "unseen word"])
+    assert seqs == [[3, 2, 1, 7, 4, 5], [1, 1]]          # cat (9) >= top_k -> <unk>; runs (7) kept
+    vec = pad_sequences_post(seqs)
+    assert vec.shape == (2, 6) and vec[1].tolist() == [1, 1, 0, 0, 0, 0]
