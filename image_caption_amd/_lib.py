@@ -157,6 +157,7 @@ SIGNATURES = {
     "icap_engine_merged_launch": ([_P], C.c_int),
     "icap_engine_fold_fc": ([_P], C.c_int),
     "icap_engine_att_table": ([_P], C.c_int),
+    "icap_engine_small_loop": ([_P], C.c_int),
     "icap_engine_decode_status": ([_P, C.POINTER(C.c_int32), _P], C.c_int),
     "icap_engine_debug_sync_state": ([_P, _P, C.POINTER(C.c_int32)], C.c_int),
     "icap_engine_set_fused_vocab": ([_P, _I], C.c_int),

@@ -17,11 +17,11 @@ constexpr int ATT_THREADS = 256;
 
 // A workgroup walks work items blockIdx.x, blockIdx.x + gridDim.x, ... (the grid may be
 // capped, see attention_f32).
-template <int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH>
+template <int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool X16 = false>
 __global__ __launch_bounds__(ATT_THREADS) void attention_f32_kernel(AttArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.high_prio) __builtin_amdgcn_s_setprio(3);
-  attention_body<ATT_THREADS, RB, UCH, VEC, ACT>(p, smem, blockIdx.x, gridDim.x);
+  attention_body<ATT_THREADS, RB, UCH, VEC, ACT, false, X16>(p, smem, blockIdx.x, gridDim.x);
 }
 
 // Query projection + attention in one launch (attention_fq_body), shaped to sit beside two
@@ -35,6 +35,12 @@ __global__ __launch_bounds__(ATT_THREADS, RB <= 3 ? 5 : 4) void attention_fq_ker
 
 template <int RB, int UCH>
 int launch_attention(const AttArgs& a, bool vec, size_t smem, hipStream_t s) {
+  if (vec && a.epf16 != nullptr) {
+    hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, true, ATT_ACT_TANH, true>), dim3(a.grid),
+                       dim3(ATT_THREADS), smem, s, a);
+    ICAP_LAUNCH_CHECK("attention_f32_kernel<bf16 operands>");
+    return ICAP_OK;
+  }
   if (vec)
     hipLaunchKernelGGL((attention_f32_kernel<RB, UCH, true>), dim3(a.grid), dim3(ATT_THREADS), smem,
                        s, a);
@@ -99,6 +105,34 @@ __global__ __launch_bounds__(256) void att_exp_table_kernel(const float4* __rest
   if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(extreme, 1);
 }
 
+// The same table rounded to bf16 (round to nearest even), and a plain float32 -> bf16 copy
+// (the features): the operands of the X16 attention bodies.
+__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(uint16_t, (__bf16)lo) |
+         ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+}
+__global__ __launch_bounds__(256) void att_exp_table16_kernel(const float4* __restrict__ pf,
+                                                              uint2* __restrict__ epf16, int* extreme,
+                                                              size_t n4) {
+  constexpr float C2 = 2.88539008177792681f;  // 2 / ln 2
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 x = pf[i];
+    const float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    bad |= !(m < ATT_EXP_LIMIT);
+    epf16[i] = make_uint2(bf16_pair(__builtin_amdgcn_exp2f(x.x * C2), __builtin_amdgcn_exp2f(x.y * C2)),
+                          bf16_pair(__builtin_amdgcn_exp2f(x.z * C2), __builtin_amdgcn_exp2f(x.w * C2)));
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(extreme, 1);
+}
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float4* __restrict__ x,
+                                                      uint2* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = x[i];
+    y[i] = make_uint2(bf16_pair(v.x, v.y), bf16_pair(v.z, v.w));
+  }
+}
+
 // ---- pooled[G,D] = mean_L features (or masked sum) ----
 __global__ __launch_bounds__(256) void pool_features_kernel(const float* __restrict__ features,
                                                             const float* __restrict__ mask,
@@ -151,17 +185,19 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
                       const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                       int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
                       int activation, hipStream_t s, const float* epf = nullptr,
-                      const int* pf_extreme = nullptr);
+                      const int* pf_extreme = nullptr, const void* epf16 = nullptr,
+                      const void* features16 = nullptr);
 
 // epf / pf_extreme: the table exp(2 * pf) and its flag from attention_exp_table_f32 (optional)
 int attention_f32(const float* pf, const float* features, const float* q, const float* v,
                   float bv, const float* score_bias, const float* gate_state,
                   const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                   int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
-                  hipStream_t s, const float* epf, const int* pf_extreme) {
+                  hipStream_t s, const float* epf, const int* pf_extreme, const void* epf16,
+                  const void* features16) {
   return attention_act_f32(pf, features, q, v, bv, score_bias, gate_state, gate_w, gate_b, ctx,
                            weights, G, R, stride_g, stride_k, L, U, D, H, max_workgroups,
-                           ICAP_ATT_ACT_TANH, s, epf, pf_extreme);
+                           ICAP_ATT_ACT_TANH, s, epf, pf_extreme, epf16, features16);
 }
 
 // activation: ICAP_ATT_ACT_*; anything but tanh serves one row per group (the layer called on
@@ -170,10 +206,14 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
                       float bv, const float* score_bias, const float* gate_state,
                       const float* gate_w, float gate_b, float* ctx, float* weights, int G, int R,
                       int stride_g, int stride_k, int L, int U, int D, int H, int max_workgroups,
-                      int activation, hipStream_t s, const float* epf, const int* pf_extreme) {
+                      int activation, hipStream_t s, const float* epf, const int* pf_extreme,
+                      const void* epf16, const void* features16) {
   ICAP_REQUIRE(pf && features && q && v && ctx, "attention_f32: null pointer");
-  ICAP_REQUIRE((epf == nullptr) == (pf_extreme == nullptr) && (!epf || aligned16(epf)),
+  ICAP_REQUIRE(((epf == nullptr && epf16 == nullptr) == (pf_extreme == nullptr)) && (!epf || aligned16(epf)),
                "attention_f32: the exp table comes with its flag, 16-byte aligned");
+  ICAP_REQUIRE((epf16 == nullptr) == (features16 == nullptr) && (!epf16 || activation == ICAP_ATT_ACT_TANH) &&
+                   (!epf16 || (aligned16(epf16) && aligned16(features16) && U % 4 == 0 && D % 4 == 0)),
+               "attention_f32: the bf16 table and the bf16 features come together, aligned, with tanh");
   ICAP_REQUIRE(activation >= ICAP_ATT_ACT_TANH && activation <= ICAP_ATT_ACT_SIGMOID,
                "attention_f32: unknown activation %d", activation);
   ICAP_REQUIRE(activation == ICAP_ATT_ACT_TANH || R == 1,
@@ -188,6 +228,8 @@ int attention_act_f32(const float* pf, const float* features, const float* q, co
             0, nullptr, nullptr, nullptr};
   a.epf = epf;
   a.pf_extreme = pf_extreme;
+  a.epf16 = static_cast<const uint16_t*>(epf16);
+  a.features16 = static_cast<const uint16_t*>(features16);
   {
     // The kernel's waves raise their instruction-issue priority: beside a matrix kernel on
     // another stream they get out of its way sooner (headline shape 99.2k against 98.7k
@@ -269,6 +311,29 @@ int attention_exp_table_f32(const float* pf, float* epf, int* extreme, size_t n,
   hipLaunchKernelGGL(att_exp_table_kernel, dim3(grid), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(pf), reinterpret_cast<float4*>(epf), extreme, n4);
   ICAP_LAUNCH_CHECK("att_exp_table_kernel");
+  return ICAP_OK;
+}
+
+int attention_exp_table_bf16(const float* pf, void* epf16, int* extreme, size_t n, hipStream_t s) {
+  ICAP_REQUIRE(pf && epf16 && extreme, "attention_exp_table_bf16: null pointer");
+  ICAP_REQUIRE(n > 0 && n % 4 == 0 && aligned16(pf) && aligned16(epf16),
+               "attention_exp_table_bf16: needs a multiple of 4 elements in 16-byte aligned buffers");
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(att_exp_table16_kernel, dim3(grid), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(pf), reinterpret_cast<uint2*>(epf16), extreme, n4);
+  ICAP_LAUNCH_CHECK("att_exp_table16_kernel");
+  return ICAP_OK;
+}
+
+int to_bf16(const float* x, void* y16, size_t n, hipStream_t s) {
+  ICAP_REQUIRE(x && y16 && n > 0 && n % 4 == 0 && aligned16(x) && aligned16(y16),
+               "to_bf16: needs a multiple of 4 elements in 16-byte aligned buffers");
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<uint2*>(y16), n4);
+  ICAP_LAUNCH_CHECK("to_bf16_kernel");
   return ICAP_OK;
 }
 

@@ -47,6 +47,11 @@ struct AttArgs {
   // decode, and *pf_extreme != 0 if any |PF| reached ATT_EXP_LIMIT (then the plain form runs).
   const float* epf = nullptr;
   const int* pf_extreme = nullptr;
+  // The same table and the features as bf16 (reduced-precision mode, X16 bodies): half the bytes
+  // of the two streams that make up the step's memory traffic.  The plain form (table flagged
+  // or |q| beyond the limit) still reads pf in float32.
+  const uint16_t* epf16 = nullptr;       // [G,L,U]
+  const uint16_t* features16 = nullptr;  // [G,L,D]
 };
 
 // The factored form is used while |PF| and |q| stay below this.  exp(2x) is exp2(x * 2/ln 2);
@@ -109,12 +114,36 @@ __device__ __forceinline__ void att_load_batch(float4 (&x)[LB][CH], const float*
   }
 }
 
+// The same batch from a bf16 array: four consecutive bf16 per lane and chunk (8 bytes), widened
+// to float32 (a bf16 is the upper half of the float32 it rounds).
+template <int LB, int CH, int WAVES>
+__device__ __forceinline__ void att_load_batch16(float4 (&x)[LB][CH], const uint16_t* __restrict__ base,
+                                                 int row_elems, const int (&off)[CH], int l0, int L) {
+  uint2 raw[LB][CH];
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = min(l0 + b * WAVES, L - 1);
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      raw[b][ch] = *reinterpret_cast<const uint2*>(base + (size_t)l * row_elems + off[ch]);
+  }
+#pragma unroll
+  for (int b = 0; b < LB; ++b)
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      x[b][ch] = make_float4(__uint_as_float(raw[b][ch].x << 16), __uint_as_float(raw[b][ch].x & 0xffff0000u),
+                             __uint_as_float(raw[b][ch].y << 16), __uint_as_float(raw[b][ch].y & 0xffff0000u));
+}
+
 // RB rows are held in registers at a time; UCH = number of 256-wide chunks of U.  The
 // workgroup (NT threads) walks work items first, first + stride, ...
 // QCOH: the queries were written by other workgroups of the same launch with device-scope
 // stores and are read with device scope (VEC only).
-template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool QCOH = false>
+// X16 (VEC, tanh): the factored scores read the bf16 table p.epf16 and the context the bf16
+// features p.features16.
+template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool QCOH = false, bool X16 = false>
 __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int first, int stride) {
+  static_assert(!X16 || (VEC && ACT == ATT_ACT_TANH), "bf16 operands serve the vector path with tanh");
   constexpr int WAVES = NT / 64;
   float* s_w = reinterpret_cast<float*>(smem);
   const int sw_elems = ((p.R * p.L + 3) / 4) * 4;
@@ -182,7 +211,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
     // holds the same q4, so the decision is the same in all of them)
     bool factored = false;
     if constexpr (VEC && ACT == ATT_ACT_TANH) {
-      if (p.epf != nullptr && *p.pf_extreme == 0) {
+      if ((X16 ? p.epf16 != nullptr : p.epf != nullptr) && *p.pf_extreme == 0) {
         float mx = 0.f;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -205,7 +234,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
         }
       }
     }
-    const float* x_g = factored ? p.epf + (size_t)g * p.L * p.U : pf_g;
+    const float* x_g = (factored && !X16) ? p.epf + (size_t)g * p.L * p.U : pf_g;
+    const uint16_t* x16_g = X16 ? p.epf16 + (size_t)g * p.L * p.U : nullptr;
     // FAST: x holds exp(2 PF) and q4 exp(2 q); tanh = 1 - 2 / (1 + product)
     auto score_location = [&](const float4 (&x)[UCH], int l, auto fast) {
       constexpr bool FAST = decltype(fast)::value;
@@ -252,14 +282,19 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
 #pragma unroll
       for (int ch = 0; ch < UCH; ++ch) off[ch] = (ch * 256 + lane * 4 + 3 < p.U) ? ch * 256 + lane * 4 : 0;
       auto walk = [&](auto fast) {
+        constexpr bool FAST16 = X16 && decltype(fast)::value;  // (the plain form reads pf itself)
+        auto load = [&](float4 (&x)[LB][UCH], int l0) {
+          if constexpr (FAST16) att_load_batch16<LB, UCH, WAVES>(x, x16_g, p.U, off, l0, p.L);
+          else att_load_batch<LB, UCH, WAVES>(x, x_g, p.U, off, l0, p.L);
+        };
         float4 xa[LB][UCH], xb[LB][UCH];
-        att_load_batch<LB, UCH, WAVES>(xa, x_g, p.U, off, wave, p.L);
+        load(xa, wave);
         for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
-          att_load_batch<LB, UCH, WAVES>(xb, x_g, p.U, off, l0 + STEP, p.L);
+          load(xb, l0 + STEP);
 #pragma unroll
           for (int b = 0; b < LB; ++b)
             if (l0 + b * WAVES < p.L) score_location(xa[b], l0 + b * WAVES, fast);
-          att_load_batch<LB, UCH, WAVES>(xa, x_g, p.U, off, l0 + 2 * STEP, p.L);
+          load(xa, l0 + 2 * STEP);
 #pragma unroll
           for (int b = 0; b < LB; ++b)
             if (l0 + STEP + b * WAVES < p.L) score_location(xb[b], l0 + STEP + b * WAVES, fast);
@@ -326,13 +361,18 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
         constexpr int LB = 4, STEP = WAVES * LB;
         const int off[1] = {(d + 3 < p.D) ? d : 0};
         float4 fa[LB][1], fb[LB][1];
-        att_load_batch<LB, 1, WAVES>(fa, f_g, p.D, off, wave, p.L);
+        const uint16_t* f16_g = X16 ? p.features16 + (size_t)g * p.L * p.D : nullptr;
+        auto loadf = [&](float4 (&x)[LB][1], int l0) {
+          if constexpr (X16) att_load_batch16<LB, 1, WAVES>(x, f16_g, p.D, off, l0, p.L);
+          else att_load_batch<LB, 1, WAVES>(x, f_g, p.D, off, l0, p.L);
+        };
+        loadf(fa, wave);
         for (int l0 = wave; l0 < p.L; l0 += 2 * STEP) {
-          att_load_batch<LB, 1, WAVES>(fb, f_g, p.D, off, l0 + STEP, p.L);
+          loadf(fb, l0 + STEP);
 #pragma unroll
           for (int b = 0; b < LB; ++b)
             if (l0 + b * WAVES < p.L) add_location(fa[b][0], l0 + b * WAVES);
-          att_load_batch<LB, 1, WAVES>(fa, f_g, p.D, off, l0 + 2 * STEP, p.L);
+          loadf(fa, l0 + 2 * STEP);
 #pragma unroll
           for (int b = 0; b < LB; ++b)
             if (l0 + STEP + b * WAVES < p.L) add_location(fb[b][0], l0 + STEP + b * WAVES);

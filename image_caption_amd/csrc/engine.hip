@@ -45,6 +45,14 @@ int lstm_step_bf16(const float*, const float*, const float*, const void*, const 
                    const int32_t*, float*, float*, int, int, int, int, hipStream_t);
 int gru_step_bf16(const float*, const float*, const void*, const float*, const float*, const int32_t*,
                   float*, int, int, int, int, hipStream_t);
+struct SmallLoopArgs;
+bool small_loop_supported(int B, int W, int C, int H, int U, int L, int D, int V);
+int small_loop_decode(const icap_config& c, const icap_weights& w, const float* wout, const float* bout,
+                      const float* emb_proj, float att_v_bias, float fc3_bias, const float* pf,
+                      const float* epf, const int* pf_extreme, const float* features, float* h0, float* h1,
+                      float* cst, float* q, float* ctx, float* logits, uint8_t* fin, int32_t* len,
+                      int32_t* hist_ids, int32_t* hist_parents, float* hist_scores, float* hist_lp,
+                      unsigned* bar, int* err, int compute_units, hipStream_t s);
 int cell_gates_bf16(const float*, const float*, const void*, float*, int, int, int, hipStream_t);
 int cell_update_f32(int, const float*, const float*, const float*, const int32_t*, const float*, float*,
                     float*, int, int, int, hipStream_t);
@@ -116,12 +124,16 @@ int attention_fq_f32(const float*, const float*, const float*, float, const floa
 int attention_act_f32(const float*, const float*, const float*, const float*, float, const float*,
                       const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                       int, int, int, int, hipStream_t, const float* epf = nullptr,
-                      const int* pf_extreme = nullptr);
+                      const int* pf_extreme = nullptr, const void* epf16 = nullptr,
+                      const void* features16 = nullptr);
 int attention_f32(const float*, const float*, const float*, const float*, float, const float*,
                   const float*, const float*, float, float*, float*, int, int, int, int, int, int,
                   int, int, int, hipStream_t, const float* epf = nullptr,
-                  const int* pf_extreme = nullptr);
+                  const int* pf_extreme = nullptr, const void* epf16 = nullptr,
+                  const void* features16 = nullptr);
 int attention_exp_table_f32(const float* pf, float* epf, int* extreme, size_t n, hipStream_t s);
+int attention_exp_table_bf16(const float* pf, void* epf16, int* extreme, size_t n, hipStream_t s);
+int to_bf16(const float* x, void* y16, size_t n, hipStream_t s);
 int pool_features_f32(const float*, const float*, float*, int, int, int, hipStream_t);
 int expand_rows_f32(const float*, float*, int, int, int, float, int, hipStream_t);
 int embedding_f32(const float*, const int32_t*, float*, int, int, int, hipStream_t);
@@ -166,7 +178,7 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
 __global__ void init_beam_state_kernel(int32_t* start_ids, int32_t start_id, float* lp, int32_t* len,
                                        uint8_t* fin, int n, unsigned* words2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2) words2[i] = 0u;  // the query-tile counter and its error word
+  if (i < 4) words2[i] = 0u;  // the query-tile counter and its error word; the one-launch loop's barrier count and error word
   if (i < n) {
     start_ids[i] = start_id;
     lp[i] = 0.f;
@@ -268,6 +280,12 @@ struct icap_engine {
   bool a16 = true;               // bf16 mode: bf16 hand-over between fc1 and the projection (ICAP_BF16_A16=0: off)
   // bf16 mode, side-stream schedule: the cell step as two launches (cell_gates_bf16 on the side
   // stream behind the attention, cell_update_f32 on the caller's stream behind the beam step)
+  // greedy decodes of a few dozen rows: the whole step loop in one cooperative launch
+  // (csrc/persistent.hip).  Opt-in, ICAP_SMALL_LOOP=1 at creation: measured at 32 rows its
+  // three grid barriers per step (4 to 9 us each across 256 workgroups) cost more than the
+  // launches they replace (78 us per step against 48).
+  bool small_loop = false;
+  int compute_units = 0;
   bool split_cell = false;
   float* zgates = nullptr;       // [N][4H] gate pre-activations of the next step
   // fc1 and fc2 have no activation between them (decoder/lstm_recurrent_decoder.py:41-42,
@@ -295,6 +313,13 @@ struct icap_engine {
   // (null: the attention kernels take the plain form; ICAP_ATT_TABLE=0)
   float* epf = nullptr;
   int* pf_extreme = nullptr;
+  // bf16 mode on the side-stream schedule, opt-in (ICAP_ATT_BF16=1): that table and the features
+  // as bf16 instead - the attention kernel's two streams at half the bytes.  Off by default:
+  // the kernel alone gets shorter, the decode does not (192.9k captions/s either way at B = 512,
+  // beam 5; the attention is hidden beside the projection), and the scores then differ from the
+  // float32-table form in the last bf16 digit.
+  uint16_t* epf16 = nullptr;
+  uint16_t* feat16 = nullptr;
   // The device word that the last enqueued decode's in-launch hand-over raises when one of its
   // bounded waits ran out (null: that decode had no such wait); icap_engine_decode_status reads it
   int* last_err = nullptr;
@@ -330,6 +355,11 @@ __global__ __launch_bounds__(256) void fold_fc_kernel(const float* __restrict__ 
   for (int j = 0; j < H; ++j) acc += (double)left[j] * (double)w2[(size_t)j * V + v];
   if (k < H) w12[(size_t)k * V + v] = (float)acc;
   else b12[v] = (float)(acc + (double)b2[v]);
+}
+
+bool prop_cooperative(int device) {
+  int v = 0;
+  return hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && v != 0;
 }
 
 struct Carver {
@@ -452,11 +482,15 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
     ICAP_TRY(engine_dense(e, icap_engine::PK_W1, features, w.att_w1_kernel, w.att_w1_bias, e->pf,
                           BL, c.D, c.U, ICAP_ACT_NONE, s));
   }
-  if (e->epf) {  // exp(2 PF) for the factored tanh scores of every step's attention
+  if (e->epf || e->epf16) {  // exp(2 PF) for the factored tanh scores of every step's attention
     Timed t(e, ICAP_K_FEAT_PROJ, s);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, e->pf_extreme, 0, 1);
     ICAP_LAUNCH_CHECK("fill_i32_kernel");
-    ICAP_TRY(attention_exp_table_f32(e->pf, e->epf, e->pf_extreme, (size_t)BL * c.U, s));
+    if (e->epf) ICAP_TRY(attention_exp_table_f32(e->pf, e->epf, e->pf_extreme, (size_t)BL * c.U, s));
+    if (e->epf16) {
+      ICAP_TRY(attention_exp_table_bf16(e->pf, e->epf16, e->pf_extreme, (size_t)BL * c.U, s));
+      ICAP_TRY(to_bf16(features, e->feat16, (size_t)BL * c.D, s));
+    }
   }
   LogitMasks masks;
   if (lv.mask_start) masks.start_col = c.start_id;
@@ -552,7 +586,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
       ICAP_TRY(attention_f32(e->pf, features, e->q, w.att_v_kernel, e->att_v_bias, nullptr,
                              state, w.fc3_kernel, e->fc3_bias, e->ctx, nullptr, c.B, c.W, stride_g,
                              stride_k, c.L, c.U, c.D, c.H, st == s ? 0 : e->side_att_wgs, st, e->epf,
-                             e->pf_extreme));
+                             e->pf_extreme, e->epf16, e->feat16));
     }
     return ICAP_OK;
   };
@@ -605,6 +639,25 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   //   main: cell_t -> fc1_t -> vocab_t -> beam_t -> cell_{t+1} ...
   //   side:     \-> query_{t+1} -> attention_{t+1} -> gates_{t+1} -/
   const bool split_cell = e->split_cell && side && bf16;
+  if (e->small_loop && topk == 0 && !masks.any() && e->overlap && fold && !gru) {
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capture) != hipSuccess) (void)hipGetLastError();
+    if (capture == hipStreamCaptureStatusNone) {  // (a cooperative launch is not captured)
+      int* err = reinterpret_cast<int*>(e->q_done + 3);
+      {
+        Timed tm(e, ICAP_K_VOCAB, s);
+        ICAP_TRY(small_loop_decode(c, w, vw, vb, e->emb_proj, e->att_v_bias, e->fc3_bias, e->pf, e->epf,
+                                   e->pf_extreme, features, e->h[0], e->h[1], e->c, e->q, e->ctx, e->logits,
+                                   e->fin, e->len, e->hist_ids, e->hist_parents, e->hist_scores, e->hist_lp,
+                                   e->q_done + 2, err, e->compute_units, s));
+      }
+      Timed tm(e, ICAP_K_BACKTRACK, s);
+      e->last_err = err;
+      ICAP_TRY(backtrack_guarded(e->hist_ids, e->hist_parents, e->hist_scores + (size_t)(c.T - 1) * N, e->fin,
+                                 tokens, nullptr, best_score, c.T, c.B, c.W, err, s));
+      return ICAP_OK;
+    }
+  }
   int cur = 0;
   ICAP_TRY(attention_step(s, gru ? e->h[cur] : e->c));
   if (split_cell) {
@@ -1125,7 +1178,15 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   // (ICAP_ATT_TABLE=0, read per engine: no table, the attention kernels evaluate tanh directly)
   const char* table_env = getenv("ICAP_ATT_TABLE");
   const bool att_table = !(table_env && table_env[0] == '0') && (BL * c.U) % 4 == 0;
-  const size_t o_epf = cv.take<float>(att_table ? BL * c.U : 0), o_ext = cv.take<int>(64);
+  // bf16 mode: the table and the features as bf16 for the side-stream attention kernel; the
+  // float32 table only for the bf16 form of the merged launch (ICAP_MERGED=1), which reads that
+  const char* a16_env0 = getenv("ICAP_ATT_BF16");
+  const char* merged_env0 = getenv("ICAP_MERGED");
+  const bool att16 = att_table && c.precision == ICAP_PRECISION_BF16 && a16_env0 && a16_env0[0] == '1' &&
+                     !(merged_env0 && merged_env0[0] == '1') && (BL * c.D) % 4 == 0 && c.U % 4 == 0 &&
+                     c.D % 4 == 0;
+  const size_t o_epf = cv.take<float>(att_table && !att16 ? BL * c.U : 0), o_ext = cv.take<int>(64);
+  const size_t o_epf16 = cv.take<uint16_t>(att16 ? BL * c.U : 0), o_f16 = cv.take<uint16_t>(att16 ? BL * c.D : 0);
   const size_t o_fc116 =  // (rows rounded up to the 32-row operand blocks of the resident kernel)
       cv.take<uint16_t>(c.precision == ICAP_PRECISION_BF16 ? (N + 31) / 32 * 32 * c.H : 0);
   // (ICAP_BF16_SPLIT_CELL=1, read per engine: the cell step of the bf16 side-stream schedule as
@@ -1201,6 +1262,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
     // B=512, W=5), so it runs uncapped there.  Tuning knob ICAP_SIDE_ATT_WGS: 0 = uncapped.
     hipDeviceProp_t prop;
     err = hipGetDeviceProperties(&prop, e->device);
+    if (err == hipSuccess) e->compute_units = prop.multiProcessorCount;
     static const char* cap_env = getenv("ICAP_SIDE_ATT_WGS");
     if (err == hipSuccess)
       // (bf16 mode: uncapped, except beams of 4 and 5 whose images divide evenly over one
@@ -1304,8 +1366,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   e->tile_rows_done = (unsigned*)(b + o_trd);
   e->q_done = (unsigned*)(b + o_qd);
   if (att_table) {
-    e->epf = (float*)(b + o_epf);
+    if (!att16) e->epf = (float*)(b + o_epf);
     e->pf_extreme = (int*)(b + o_ext);
+    if (att16) {
+      e->epf16 = (uint16_t*)(b + o_epf16);
+      e->feat16 = (uint16_t*)(b + o_f16);
+    }
   }
   {
     // opt-in (ICAP_BEAM_IN_LAUNCH=1, read per engine): measured 7 % slower than the separate
@@ -1317,6 +1383,12 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
         dense_topk_beam_supported((int)N, c.W, dense_topk_half_tiles(c.V), e->topk_able, 1, 0);
   }
   e->fc1o16 = (uint16_t*)(b + o_fc116);
+  {
+    const char* sl_env = getenv("ICAP_SMALL_LOOP");  // tuning knob, read per engine
+    e->small_loop = c.precision == ICAP_PRECISION_FP32 && c.cell == ICAP_CELL_LSTM && e->compute_units > 0 &&
+                    small_loop_supported(c.B, c.W, c.D, c.H, c.U, c.L, c.D, c.V) && prop_cooperative(e->device) &&
+                    sl_env && sl_env[0] == '1';
+  }
   e->split_cell = split_cell;
   if (split_cell) e->zgates = (float*)(b + o_zg);
   {
@@ -1514,7 +1586,9 @@ int icap_engine_merged_launch(const icap_engine* e) {
 
 int icap_engine_fold_fc(const icap_engine* e) { return e && e->fold && e->w12 ? 1 : 0; }
 
-int icap_engine_att_table(const icap_engine* e) { return e && e->epf ? 1 : 0; }
+int icap_engine_att_table(const icap_engine* e) { return e && (e->epf || e->epf16) ? 1 : 0; }
+
+int icap_engine_small_loop(const icap_engine* e) { return e && e->small_loop ? 1 : 0; }
 
 int icap_engine_decode_status(icap_engine* e, int32_t* invalid, icap_stream_t stream) {
   ICAP_REQUIRE(e && invalid, "icap_engine_decode_status: null argument");

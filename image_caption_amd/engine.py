@@ -269,6 +269,12 @@ class CaptionEngine:
         """True when the attention scores use the per-decode exp(2 PF) table."""
         return bool(_lib.load().icap_engine_att_table(self._handle))
 
+    @property
+    def small_loop(self):
+        """True when greedy decodes run their whole step loop as one cooperative launch
+        (ICAP_SMALL_LOOP=1 when the engine was created, supported shapes only)."""
+        return bool(_lib.load().icap_engine_small_loop(self._handle))
+
     def set_fold_fc(self, on):
         """True (default in fp32 / split mode): project the cell output with the folded
         fc1 . fc2 kernel; False: the reference's two products."""

@@ -502,6 +502,14 @@ int icap_engine_merged_launch(const icap_engine* engine);
  * counterpart in the reference; they exist so that a benchmark line can say what it ran. */
 int icap_engine_fold_fc(const icap_engine* engine);
 int icap_engine_att_table(const icap_engine* engine);
+/* 1 when greedy decodes of this engine (beam width 1, no masks, fp32, LSTM, a few dozen rows)
+ * run their whole step loop (/root/reference/recurrent_example.py:517-558) as ONE cooperative
+ * launch instead of five launches per step.  Opt-in: ICAP_SMALL_LOOP=1 in the environment when
+ * the engine is created, and only for shapes the launch supports; the launch-per-kernel loop
+ * is the default because it is the faster one on MI355X.  Same tokens and history either
+ * way; the waits between its phases are bounded and a wait that runs out is reported through
+ * icap_engine_decode_status like the merged launch's. */
+int icap_engine_small_loop(const icap_engine* engine);
 /* Validity of the last decode enqueued on this engine (icap_decode / icap_search_baseline).
  * The merged launch (icap_engine_merged_launch) hands the query projection q over INSIDE one
  * launch: its query tiles store q through to device scope and count themselves on a device

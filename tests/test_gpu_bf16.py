@@ -260,3 +260,11 @@ def test_engine_bf16_paired_k_stages_give_the_same_bits(monkeypatch):
     for k in ("ids", "parents"):
         np.testing.assert_array_equal(tr0[k], tr1[k])
     np.testing.assert_array_equal(tr0["scores"].view(np.uint32), tr1["scores"].view(np.uint32))
+
+
+def test_engine_bf16_attention_on_bf16_table_and_features(monkeypatch):
+    """ICAP_ATT_BF16=1 (opt-in): the attention kernel reads exp(2 PF) and the features as bf16.
+    Same bar as the mode itself: scores within 1e-2 of the fp32 oracle's at production width,
+    token divergences only at near ties."""
+    monkeypatch.setenv("ICAP_ATT_BF16", "1")
+    test_engine_bf16_against_fp32_oracle(8, 5, 6, (64, 2048, 256, 256, 512, 10000))

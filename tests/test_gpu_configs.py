@@ -48,11 +48,52 @@ def test_config1_greedy_b32_against_oracle(fused, peaked):
         assert len({tuple(r) for r in tok.tolist()}) >= 16      # captions differ per image
 
 
+SMALL = dict(F=48, D=128, E=32, H=128, V=200)
+MID = dict(F=64, D=256, E=64, H=256, V=1000)
+
+
+@pytest.mark.parametrize("dims,B,L,T,peaked", [(SMALL, 5, 6, 6, True), (SMALL, 40, 6, 6, False),
+                                               (MID, 33, 9, 8, True), (PROD, 32, 64, 20, True),
+                                               (PROD, 64, 64, 20, False)])
+def test_greedy_decode_in_one_cooperative_launch(monkeypatch, dims, B, L, T, peaked):
+    """ICAP_SMALL_LOOP=1: the whole greedy step loop as one launch, against the oracle step by
+    step and against the launch-per-kernel loop (the two accumulate their products in different
+    orders: tokens equal except where Keras-default weights tie, scores within 1e-4)."""
+    from image_caption_amd.engine import CaptionConfig, CaptionEngine
+    p = (co.make_peaked_params if peaked else co.make_params)(B, **dims)
+    p = co.perturb_biases(p, B + 1)
+    img = co.make_images(B + 2, B, L, dims["F"])
+    cfg = CaptionConfig(B=B, W=1, L=L, F=dims["F"], D=dims["D"], E=dims["E"], H=dims["H"],
+                        U=dims["H"], V=dims["V"], T=T, start_id=3, eos_id=4)
+    monkeypatch.setenv("ICAP_SMALL_LOOP", "1")
+    eng = CaptionEngine(cfg, p, device=dev())
+    assert eng.small_loop
+    tok, sc = eng.decode(to_dev(img), check=True)
+    tr = {k: np_of(v) for k, v in eng.trace().items()}
+    tok, sc = np_of(tok), np_of(sc)
+    # a second decode on the same engine (the barrier words start from zero again)
+    tok2, _ = eng.decode(to_dev(img), check=True)
+    np.testing.assert_array_equal(np_of(tok2), tok)
+    eng.close()
+    nbad, ties = check_decode_following(p, img, 1, T, 3, 4, 1.0, "reference", tok, tr)
+    assert nbad <= (0 if peaked else 2), ties
+    monkeypatch.delenv("ICAP_SMALL_LOOP")
+    ref = CaptionEngine(cfg, p, device=dev())
+    assert not ref.small_loop
+    rtok, rsc = ref.decode(to_dev(img))
+    rtok, rsc = np_of(rtok), np_of(rsc)
+    ref.close()
+    same = (rtok == tok).all(axis=-1).reshape(-1)
+    assert same.sum() >= B - (0 if peaked else 2)
+    np.testing.assert_allclose(sc.reshape(-1)[same], rsc.reshape(-1)[same], rtol=1e-4, atol=1e-4)
+
+
 def test_config1_default_path_is_the_small_batch_one():
     from image_caption_amd.engine import CaptionConfig, CaptionEngine
     eng = CaptionEngine(CaptionConfig(B=32, W=1, L=64, T=2, **{k: PROD[k] for k in "FDEHV"},
                                       U=PROD["H"]), co.make_params(0, **PROD), device=dev())
     assert not eng.fused_vocab
+    assert not eng.small_loop           # the one-launch loop is opt-in
     eng.close()
 
 

@@ -2,7 +2,7 @@
 engine on the whole batch (does the latency-bound part of one decode - LSTM, fc1, beam step,
 launch gaps - hide under the other's vocab projection?).
 
-    python tools/overlap_probe_lstm.py [precision]
+    python tools/overlap_probe_lstm.py [precision [beam width]]
 """
 import sys
 import time
@@ -15,12 +15,13 @@ from image_caption_amd.engine import CaptionConfig, CaptionEngine  # noqa: E402
 
 dev = torch.device("cuda", 0)
 precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 params = synthetic.make_params(0, F=2048, D=256, E=256, H=512, V=10000)
 params = {k: torch.from_numpy(v).to(dev) for k, v in params.items()}
 
 
 def run(nb, B, reps=20, fused=None):
-    engs = [CaptionEngine(CaptionConfig(B=B, W=3, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000,
+    engs = [CaptionEngine(CaptionConfig(B=B, W=W, L=64, F=2048, D=256, E=256, H=512, U=512, V=10000,
                                         T=20, precision=precision), params, device=dev)
             for _ in range(nb)]
     if fused is not None:
