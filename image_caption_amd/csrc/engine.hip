@@ -280,7 +280,7 @@ struct icap_engine {
   bool a16 = true;               // bf16 mode: bf16 hand-over between fc1 and the projection (ICAP_BF16_A16=0: off)
   // bf16 mode, side-stream schedule: the cell step as two launches (cell_gates_bf16 on the side
   // stream behind the attention, cell_update_f32 on the caller's stream behind the beam step)
-  // greedy decodes of a few dozen rows: the whole step loop in one cooperative launch
+  // greedy decodes of a few dozen rows: the whole step loop in one launch of resident workgroups
   // (csrc/persistent.hip).  Opt-in, ICAP_SMALL_LOOP=1 at creation: measured at 32 rows its
   // three grid barriers per step (4 to 9 us each across 256 workgroups) cost more than the
   // launches they replace (78 us per step against 48).
@@ -355,11 +355,6 @@ __global__ __launch_bounds__(256) void fold_fc_kernel(const float* __restrict__ 
   for (int j = 0; j < H; ++j) acc += (double)left[j] * (double)w2[(size_t)j * V + v];
   if (k < H) w12[(size_t)k * V + v] = (float)acc;
   else b12[v] = (float)(acc + (double)b2[v]);
-}
-
-bool prop_cooperative(int device) {
-  int v = 0;
-  return hipDeviceGetAttribute(&v, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && v != 0;
 }
 
 struct Carver {
@@ -642,7 +637,7 @@ int decode_impl(icap_engine* e, const float* img, int32_t* tokens, float* best_s
   if (e->small_loop && topk == 0 && !masks.any() && e->overlap && fold && !gru) {
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &capture) != hipSuccess) (void)hipGetLastError();
-    if (capture == hipStreamCaptureStatusNone) {  // (a cooperative launch is not captured)
+    if (capture == hipStreamCaptureStatusNone) {  // (captured decodes keep the launch-per-kernel loop)
       int* err = reinterpret_cast<int*>(e->q_done + 3);
       {
         Timed tm(e, ICAP_K_VOCAB, s);
@@ -1386,7 +1381,7 @@ int icap_engine_create(const icap_config* config, const icap_weights* weights, i
   {
     const char* sl_env = getenv("ICAP_SMALL_LOOP");  // tuning knob, read per engine
     e->small_loop = c.precision == ICAP_PRECISION_FP32 && c.cell == ICAP_CELL_LSTM && e->compute_units > 0 &&
-                    small_loop_supported(c.B, c.W, c.D, c.H, c.U, c.L, c.D, c.V) && prop_cooperative(e->device) &&
+                    small_loop_supported(c.B, c.W, c.D, c.H, c.U, c.L, c.D, c.V) &&
                     sl_env && sl_env[0] == '1';
   }
   e->split_cell = split_cell;

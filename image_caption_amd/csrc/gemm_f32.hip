@@ -50,7 +50,25 @@ struct DenseArgs {
   // Device-side switch (engine only, null otherwise): the launch does nothing unless
   // *run_flag != 0.
   const int* run_flag = nullptr;
+  int band_width = 0;  // band_order 1: panels per band (0: an eighth of the panels)
 };
+
+// Panels per band of the band tile order (tile_of_block_band).  An XCD sweeps a band with the
+// panel index fastest, so the band's slice of the weights is what has to stay in its 4 MB L2
+// while the activations stream through once per band.  An eighth of a 10 000-word vocabulary
+// (10 panels of 256 KB at K = 512) nearly does; an eighth of 50 000 words (49 panels, 12.8 MB)
+// does not, and every M tile then fetches the whole band again: 2.4 GB of L2 fills per launch at
+// 2560 rows x 50 000 words against 0.90 GB with bands of 6 panels (8: 1.19 GB, 4: 0.99 GB,
+// 3: 1.14 GB, 2: 1.41 GB; the launch is bound by the matrix pipe, so the rate moves by half a
+// percent).  Hence: bands of at most 1.5 MB.  Tuning knob ICAP_BAND_WIDTH (0 = eighths).
+inline int band_width_for(int K, int tiles_n) {
+  static const char* bw_env = getenv("ICAP_BAND_WIDTH");
+  if (bw_env) return atoi(bw_env);
+  const size_t panel_bytes = (size_t)K * 128 * sizeof(float);
+  const int eighth = (tiles_n + 7) / 8;
+  const int fit = (int)(((size_t)3 << 19) / panel_bytes);
+  return eighth <= fit ? 0 : (fit < 1 ? 1 : fit);
+}
 
 // Guarded 4-float load without control flow: the address is clamped to `safe` (any
 // readable 16-byte aligned location) when the vector is out of range and the result
@@ -271,7 +289,7 @@ __device__ __forceinline__ int dense_fast_body(const DenseArgs& p, int block,
   auto& Bs = lds.st.Bs;
 
   int tile_m, tile_n;
-  if (p.band_order) tile_of_block_band(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  if (p.band_order) tile_of_block_band(block, p.tiles_m, p.tiles_n, tile_m, tile_n, p.band_width);
   else tile_of_block(block, p.tiles_m, p.tiles_n, tile_m, tile_n);
   const int m0 = tile_m * BMG + sub * BM;
   const int n0 = tile_n * BN;
@@ -1577,6 +1595,7 @@ int dense_f32_flagged(const float* x, int lda, const float* w, const float* bias
                "dense_f32_flagged: shape not served (M=%d K=%d N=%d lda=%d)", M, K, N, lda);
   DenseArgs a{x, w, bias, y, M, N, K, lda, N, N, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};
   a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  a.band_width = band_width_for(K, a.tiles_n);
   a.run_flag = run_flag;
   return launch_dense<128, 128, 4, 2, 2>(a, true, s);
 }
@@ -1616,6 +1635,7 @@ int dense_topk_f32_strided(const float* x, int lda, const float* w, const float*
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, 128);
   a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  a.band_width = band_width_for(K, a.tiles_n);
   // (96-row tiles would leave fewer compute units idle at the end - 4.94 tiles per CU
   // instead of 3.70 at 1536 x 10000 - but their six waves spread unevenly over the four
   // SIMDs: measured 197 us against 146 us)
@@ -1750,6 +1770,7 @@ int dense_topk_attention_f32(const float* x, int lda, const float* w, const floa
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, 128);
   a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  a.band_width = band_width_for(K, a.tiles_n);
   att_blocks = att_blocks > 0 ? (att_blocks < G ? att_blocks : G) : G;
   if (att_blocks >= 8) att_blocks &= ~7;  // the tile workgroups keep their XCD
   AttArgs t{pf, features, nullptr, att_v, att_bv, nullptr, state, gate_w, gate_b, ctx, nullptr,
@@ -1822,6 +1843,7 @@ int dense_topk_attq_f32(const float* x, int lda, const float* w, const float* bi
   a.tiles_m = ceil_div(M, 128);
   a.tiles_n = ceil_div(N, 128);
   a.band_order = (size_t)M * K * sizeof(float) > (size_t)(5 << 19) ? 1 : 0;
+  a.band_width = band_width_for(K, a.tiles_n);
   // q = state . q_w + q_b over all G*R rows, 64 x 128 tiles
   const int rows = G * R;
   DenseArgs aq{state, q_w, q_b, q, rows, U, H, H, U, U, ICAP_ACT_NONE, 0, 0, 0, nullptr, nullptr, -1};

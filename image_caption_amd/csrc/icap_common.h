@@ -115,13 +115,17 @@ __device__ __forceinline__ void tile_of_block(int pid, int tiles_m, int tiles_n,
 // panels with the panel index fastest and the M tile slowest.  The band of B panels stays
 // in the XCD's L2 while every A tile is fetched once per XCD and reused across the band
 // by consecutive workgroups - the order for tall A operands that do not fit in one L2.
+// `width` > 0 narrows the bands to that many panels (an XCD then sweeps several bands one
+// after the other): for B operands whose eighth does not fit in an L2 either - a band of
+// `width` panels does, and the A operand is fetched once per band instead of B once per M tile.
 __device__ __forceinline__ void tile_of_block_band(int pid, int tiles_m, int tiles_n, int& tm,
-                                                   int& tn) {
+                                                   int& tn, int width_limit = 0) {
   const int total = tiles_m * tiles_n;
   const int q = total >> 3, r = total & 7;
   const int xcd = pid & 7;
   const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pid >> 3);
-  const int pw = (tiles_n + 7) >> 3;        // panels per band
+  const int pw8 = (tiles_n + 7) >> 3;
+  const int pw = width_limit > 0 ? min(width_limit, pw8) : pw8;  // panels per band
   const int band_tiles = tiles_m * pw;
   const int band = sid / band_tiles;
   const int in_band = sid - band * band_tiles;

@@ -3,7 +3,7 @@
 // At beam width 1 and 32 images a decode step is five short kernels (cell, query, attention,
 // vocab projection, beam step) of 8 to 15 us each, most of it launch and drain: the products
 // are weight streams of 1 to 20 MB and the rest is a few hundred kilobytes.  Here one
-// cooperative grid (one workgroup of 16 waves per compute unit) stays resident for all T steps
+// grid (one workgroup of 16 waves per compute unit) stays resident for all T steps
 // (recurrent_example.py:517-558) and walks three phases per step, separated by grid barriers:
 //
 //   L   cell step            [ctx | h] . [K; R] + emb_proj[id] + b, LSTM update   H/8 blocks per 32 rows
@@ -428,7 +428,15 @@ bool small_loop_supported(int B, int W, int C, int H, int U, int L, int D, int V
   return sizeof(float) * attention_lds_floats(SL_NT, 1, 1, L, D) <= (size_t)SL_LDS_BYTES - 64;
 }
 
-// The grid: one workgroup per compute unit, all resident at once (cooperative launch).
+// The grid: one workgroup per compute unit (a workgroup of 16 waves and 72 KB of LDS is alone
+// on its unit).  An ordinary launch, not a cooperative one: the runtime keeps a hardware queue
+// of its own for cooperative launches, and on this driver one more queue in the process is
+// what stalls event waits between the legacy default stream and other streams later on.
+// Without the runtime's guarantee that the whole grid is resident at once the barriers lean
+// on the dispatcher placing every workgroup as units fall free - true whenever no other
+// resident kernel waits for this one; two of these loops enqueued on different streams of
+// one GPU can each hold part of the units and then both run into the bounded wait, which ends
+// them with *err raised (-1 tokens, reported by the engine's decode status) instead of a hang.
 int small_loop_f32(const SmallLoopArgs& args, int compute_units, hipStream_t s) {
   const SmallLoopArgs& p = args;
   ICAP_REQUIRE(small_loop_supported(p.B, 1, p.C, p.H, p.U, p.L, p.D, p.V), "small_loop_f32: shape not served");
@@ -441,7 +449,10 @@ int small_loop_f32(const SmallLoopArgs& args, int compute_units, hipStream_t s) 
   ICAP_REQUIRE(fn != nullptr, "small_loop_f32: no instance for these sizes");
   SmallLoopArgs copy = args;
   void* kargs[] = {&copy};
-  ICAP_HIP(hipLaunchCooperativeKernel(fn, dim3(compute_units), dim3(SL_NT), kargs, 0, s));
+  static const char* grid_env = getenv("ICAP_SMALL_LOOP_GRID");  // tuning knob: fewer workgroups
+  const int grid = grid_env && atoi(grid_env) > 0 && atoi(grid_env) < compute_units ? atoi(grid_env) : compute_units;
+  ICAP_REQUIRE(grid >= p.B, "small_loop_f32: the grid must hold one workgroup per row");
+  ICAP_HIP(hipLaunchKernel(fn, dim3(grid), dim3(SL_NT), kargs, 0, s));
   return ICAP_OK;
 }
 
