@@ -237,22 +237,39 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
     const float* x_g = (factored && !X16) ? p.epf + (size_t)g * p.L * p.U : pf_g;
     const uint16_t* x16_g = X16 ? p.epf16 + (size_t)g * p.L * p.U : nullptr;
     // FAST: x holds exp(2 PF) and q4 exp(2 q); tanh = 1 - 2 / (1 + product)
+    // FAST, two elements per reciprocal (the reciprocal runs at a quarter of the vector rate
+    // and is half of an element's cost): with d = 1 + exp(2 PF) exp(2 q),
+    //   sum v (1 - 2 / d) = sum v + sum_pairs ((-2 v1) d2 + (-2 v2) d1) / (d1 d2)
+    // d <= 1 + e^40 below the limit, so the product of two stays far inside the float range.
+    float vsum = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < UCH; ++ch) vsum += (v4[ch].x + v4[ch].y) + (v4[ch].z + v4[ch].w);
     auto score_location = [&](const float4 (&x)[UCH], int l, auto fast) {
       constexpr bool FAST = decltype(fast)::value;
-      auto term = [&](float xv, float qv) -> float {
-        if constexpr (FAST) return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(xv, qv, 1.0f)), 1.0f);
-        else return att_act<ACT>(xv + qv);
+      auto pair = [&](float x1, float q1, float v1, float x2, float q2, float v2, float acc) -> float {
+        const float d1 = __builtin_fmaf(x1, q1, 1.0f), d2 = __builtin_fmaf(x2, q2, 1.0f);
+        const float n = __builtin_fmaf(-2.0f * v2, d1, (-2.0f * v1) * d2);
+        return __builtin_fmaf(n, __builtin_amdgcn_rcpf(d1 * d2), acc);
       };
       float a[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        a[r] = 0.f;
+        if constexpr (FAST) {
+          a[r] = vsum;
 #pragma unroll
-        for (int ch = 0; ch < UCH; ++ch) {
-          a[r] += v4[ch].x * term(x[ch].x, q4[r][ch].x);
-          a[r] += v4[ch].y * term(x[ch].y, q4[r][ch].y);
-          a[r] += v4[ch].z * term(x[ch].z, q4[r][ch].z);
-          a[r] += v4[ch].w * term(x[ch].w, q4[r][ch].w);
+          for (int ch = 0; ch < UCH; ++ch) {
+            a[r] = pair(x[ch].x, q4[r][ch].x, v4[ch].x, x[ch].y, q4[r][ch].y, v4[ch].y, a[r]);
+            a[r] = pair(x[ch].z, q4[r][ch].z, v4[ch].z, x[ch].w, q4[r][ch].w, v4[ch].w, a[r]);
+          }
+        } else {
+          a[r] = 0.f;
+#pragma unroll
+          for (int ch = 0; ch < UCH; ++ch) {
+            a[r] += v4[ch].x * att_act<ACT>(x[ch].x + q4[r][ch].x);
+            a[r] += v4[ch].y * att_act<ACT>(x[ch].y + q4[r][ch].y);
+            a[r] += v4[ch].z * att_act<ACT>(x[ch].z + q4[r][ch].z);
+            a[r] += v4[ch].w * att_act<ACT>(x[ch].w + q4[r][ch].w);
+          }
         }
       }
       float part[RB];
@@ -276,6 +293,9 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
     if constexpr (VEC) {
       // two register sets of LB locations each: the next set's loads are in flight while the
       // current one is scored (same locations per wave and same order as the plain loop)
+      // (More rows in flight do not pay beside the projection: at beam 5, 4 or 8 instead of 2
+      // locations per set take the kernel from 161 to 182 / 256 registers, it no longer fits
+      // beside the projection's waves and the decode drops from 190k to 156k / 150k captions/s.)
       constexpr int LB = (RB * UCH <= 6 && NT <= 256) ? 4 : 2;  // (512-thread form: inside a projection launch, 128 registers)
       constexpr int STEP = WAVES * LB;
       int off[UCH];

@@ -271,7 +271,7 @@ class CaptionEngine:
 
     @property
     def small_loop(self):
-        """True when greedy decodes run their whole step loop as one cooperative launch
+        """True when greedy decodes run their whole step loop as one launch of resident workgroups
         (ICAP_SMALL_LOOP=1 when the engine was created, supported shapes only)."""
         return bool(_lib.load().icap_engine_small_loop(self._handle))
 

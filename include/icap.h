@@ -503,7 +503,7 @@ int icap_engine_merged_launch(const icap_engine* engine);
 int icap_engine_fold_fc(const icap_engine* engine);
 int icap_engine_att_table(const icap_engine* engine);
 /* 1 when greedy decodes of this engine (beam width 1, no masks, fp32, LSTM, a few dozen rows)
- * run their whole step loop (/root/reference/recurrent_example.py:517-558) as ONE cooperative
+ * run their whole step loop (/root/reference/recurrent_example.py:517-558) as ONE
  * launch instead of five launches per step.  Opt-in: ICAP_SMALL_LOOP=1 in the environment when
  * the engine is created, and only for shapes the launch supports; the launch-per-kernel loop
  * is the default because it is the faster one on MI355X.  Same tokens and history either

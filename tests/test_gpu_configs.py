@@ -55,7 +55,7 @@ MID = dict(F=64, D=256, E=64, H=256, V=1000)
 @pytest.mark.parametrize("dims,B,L,T,peaked", [(SMALL, 5, 6, 6, True), (SMALL, 40, 6, 6, False),
                                                (MID, 33, 9, 8, True), (PROD, 32, 64, 20, True),
                                                (PROD, 64, 64, 20, False)])
-def test_greedy_decode_in_one_cooperative_launch(monkeypatch, dims, B, L, T, peaked):
+def test_greedy_decode_in_one_launch(monkeypatch, dims, B, L, T, peaked):
     """ICAP_SMALL_LOOP=1: the whole greedy step loop as one launch, against the oracle step by
     step and against the launch-per-kernel loop (the two accumulate their products in different
     orders: tokens equal except where Keras-default weights tie, scores within 1e-4)."""
