@@ -141,7 +141,10 @@ __device__ __forceinline__ void att_load_batch16(float4 (&x)[LB][CH], const uint
 // stores and are read with device scope (VEC only).
 // X16 (VEC, tanh): the factored scores read the bf16 table p.epf16 and the context the bf16
 // features p.features16.
-template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool QCOH = false, bool X16 = false>
+// SCOH: the gate state was written, and the context will be read, by other workgroups of the
+// same launch: device-scope loads and stores for both.
+template <int NT, int RB, int UCH, bool VEC, int ACT = ATT_ACT_TANH, bool QCOH = false, bool X16 = false,
+          bool SCOH = false>
 __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int first, int stride) {
   static_assert(!X16 || (VEC && ACT == ATT_ACT_TANH), "bf16 operands serve the vector path with tanh");
   constexpr int WAVES = NT / 64;
@@ -175,7 +178,12 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
       const int n = g * p.stride_g + k * p.stride_k;
       const float* cs = p.gate_state + (size_t)n * p.H;
       float part = 0.f;
-      for (int i = lane; i < p.H; i += 64) part += cs[i] * p.gate_w[i];
+      for (int i = lane; i < p.H; i += 64) {
+        float sv;
+        if constexpr (SCOH) sv = __hip_atomic_load(cs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else sv = cs[i];
+        part += sv * p.gate_w[i];
+      }
       part = wave_sum(part);
       beta = fast_sigmoid(part + p.gate_b);
     }
@@ -417,7 +425,10 @@ __device__ __forceinline__ void attention_body(const AttArgs& p, char* smem, int
 #pragma unroll
           for (int w = 0; w < WAVES; ++w) sum += s_part[(w * RB + r) * dpad + e];
           const int n = g * p.stride_g + k * p.stride_k;
-          p.ctx[(size_t)n * p.D + e] = sum * s_beta[k];
+          if constexpr (SCOH)
+            __hip_atomic_store(p.ctx + (size_t)n * p.D + e, sum * s_beta[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            p.ctx[(size_t)n * p.D + e] = sum * s_beta[k];
         }
       }
       __syncthreads();

@@ -14,12 +14,15 @@
 // The products use the small-batch scheme of the stand-alone kernels (a block owns 32 rows x 32
 // columns, its sixteen waves split K, operands go from memory straight into the MFMA registers,
 // partial blocks meet in LDS).  Between phases data changes hands between compute units on
-// different XCDs, whose L2s are not coherent with each other: the grid barrier is a release
-// (write-back) before the count and an acquire (invalidate) behind the wait, at device scope,
-// which is what a kernel boundary does as well.  Every wait is bounded: a barrier that runs out
-// raises *err, every workgroup leaves, and the caller turns the result into -1 tokens.
-// Words that change between phases and are uniform over a wave (ids, beam state) are read with
-// device-scope loads, never through the scalar cache, which the barrier does not invalidate.
+// different XCDs, whose L2s are not coherent with each other.  What changes hands (h, c, q, ctx,
+// the logits, ids and beam state: a few hundred kilobytes per step) is written through with
+// device-scope stores and read with device-scope loads; the grid barrier is then only a count -
+// every thread waits for its stores' acknowledgement, the workgroup adds itself to a device
+// counter and one lane polls it.  No cache-wide release or acquire: those write back and empty
+// a whole L2 per workgroup and barrier, and the 27 MB of weights that every step reads again
+// (an eighth per XCD, which its 4 MB L2 holds) would come from memory every time.
+// Every wait is bounded: a barrier that runs out raises *err, every workgroup leaves, and the
+// caller turns the result into -1 tokens.
 #include <stdlib.h>
 
 #include "attention_body.h"
@@ -63,33 +66,51 @@ namespace {
 
 constexpr int SL_NT = 1024;
 constexpr int SL_LDS_BYTES = 72 * 1024;
-constexpr unsigned SL_POLL_LIMIT = 1u << 22;  // x s_sleep(1): a few hundred milliseconds
+#ifndef SL_POLL_SLEEP
+#define SL_POLL_SLEEP 1  // x 64 clocks between two polls of a waiting workgroup
+#endif
+constexpr unsigned SL_POLL_LIMIT = 1u << 22;  // x the sleep: a few hundred milliseconds and more
 
 template <typename T>
 __device__ __forceinline__ T ld_dev(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Data that changes hands between workgroups inside the launch (h, c, q, ctx, the logits, the
+// beam state) is written with device-scope stores - through to where every XCD reads it - and
+// read with device-scope loads, which do not take a line from the reader's L2.
+template <typename T>
+__device__ __forceinline__ void st_dev(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_dev4(const float* p) {  // 16-byte aligned
+  const unsigned long long* s2 = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(s2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+
 // All workgroups of the grid meet here.  Returns false when the wait ran out (here or, as seen
 // through *err, anywhere else): the caller leaves the kernel.
 __device__ __forceinline__ bool grid_barrier(const SmallLoopArgs& p, unsigned& epoch, int* s_flag) {
+  // every thread's device-scope stores are acknowledged (written through) before the workgroup
+  // counts itself; no cache-wide fence on either side of the wait: a release would write a whole
+  // L2 back and an acquire would empty it - of the weights, which every phase of every step
+  // reads again and which nothing in the launch writes
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   epoch += 1;
   if (threadIdx.x == 0) {
     const unsigned target = epoch * gridDim.x;
-    // release: what this workgroup wrote (ordered before by the barrier above) is written back
-    // to where every XCD sees it, then the count; the polls themselves are plain device-scope
-    // loads (an acquire per poll would invalidate the L2 under the workgroups still working)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = true;
     unsigned polls = 0;
     while (ld_dev(p.bar) < target) {
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(SL_POLL_SLEEP);
       if (++polls > SL_POLL_LIMIT || ((polls & 255u) == 0 && ld_dev(p.err) != 0)) { ok = false; break; }
     }
     if (!ok) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_flag = ok ? 1 : 0;
   }
   __syncthreads();
@@ -119,7 +140,7 @@ __device__ __forceinline__ void cell_block(const SmallLoopArgs& p, int blk, int 
     const int k = k_begin + 8 * g + 4 * half;
     const bool in_ctx = k < p.C;  // C % 4 == 0: a 4-k slice never straddles the two sources
     const float* ap = in_ctx ? p.ctx + (size_t)gm * p.C + k : h_in + (size_t)gm * p.H + (k - p.C);
-    a[g] = *reinterpret_cast<const float4*>(ap);
+    a[g] = ld_dev4(ap);
     const float* bp = (in_ctx ? p.cell_kernel + (size_t)k * H4 : p.cell_recurrent + (size_t)(k - p.C) * H4) + col;
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[g][s] = bp[(size_t)s * H4];
@@ -159,9 +180,9 @@ __device__ __forceinline__ void cell_block(const SmallLoopArgs& p, int blk, int 
         z[g] = (Z2[row][g * 8 + u] + (tok ? e : 0.f)) + p.cell_bias[g * p.H + j];
       }
       const size_t o = (size_t)m * p.H + j;
-      const float c_new = fast_sigmoid(z[1]) * p.c[o] + fast_sigmoid(z[0]) * fast_tanh(z[2]);
-      p.c[o] = c_new;
-      h_out[o] = fast_sigmoid(z[3]) * fast_tanh(c_new);
+      const float c_new = fast_sigmoid(z[1]) * ld_dev(p.c + o) + fast_sigmoid(z[0]) * fast_tanh(z[2]);
+      st_dev(p.c + o, c_new);
+      st_dev(h_out + o, fast_sigmoid(z[3]) * fast_tanh(c_new));
     }
   }
   __syncthreads();  // (the next block of this workgroup reuses the LDS)
@@ -169,8 +190,8 @@ __device__ __forceinline__ void cell_block(const SmallLoopArgs& p, int blk, int 
 
 // ---- phase QV: y[M,N] = x[M,K] . w[K,N] + bias, one block = 32 rows x 32 columns ----
 template <int NG>
-__device__ __forceinline__ void dense_block(const float* __restrict__ x, const float* __restrict__ w,
-                                            const float* __restrict__ bias, float* __restrict__ y, int M,
+__device__ __forceinline__ void dense_block(const float* x, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* y, int M,
                                             int K, int N, int blk, int tiles_m, char* smem) {
   float (*Zs)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
   const int tile_m = blk % tiles_m, tile_n = blk / tiles_m;
@@ -185,7 +206,7 @@ __device__ __forceinline__ void dense_block(const float* __restrict__ x, const f
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int k = k_begin + 8 * g + 4 * half;
-    a[g] = *reinterpret_cast<const float4*>(x + (size_t)gm * K + k);
+    a[g] = ld_dev4(x + (size_t)gm * K + k);
     const float* bp = w + (size_t)k * N + col;
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[g][s] = bp[(size_t)s * N];
@@ -210,7 +231,7 @@ __device__ __forceinline__ void dense_block(const float* __restrict__ x, const f
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) sum += Zs[i][row][cc];
-      y[(size_t)m * N + n] = sum + (bias ? bias[n] : 0.f);
+      st_dev(y + (size_t)m * N + n, sum + (bias ? bias[n] : 0.f));
     }
   }
   __syncthreads();
@@ -265,9 +286,9 @@ __device__ __forceinline__ void greedy_row(const SmallLoopArgs& p, int b, int t,
         if (cand_better(sc, col, bs, bi)) { bs = sc; bt = total; bi = col; }
       }
       p.hist_scores[o] = bs;
-      p.hist_ids[o] = bi < 0 ? 0 : bi;
+      st_dev(p.hist_ids + o, bi < 0 ? 0 : bi);
       p.hist_parents[o] = 0;
-      p.hist_lp[o] = bt;
+      st_dev(p.hist_lp + o, bt);
       // (finished stays set, the length stays)
     }
     return;
@@ -276,7 +297,7 @@ __device__ __forceinline__ void greedy_row(const SmallLoopArgs& p, int b, int t,
   // statistics: max, sum of exp, and the best logit outside the eos column
   float m = -INFINITY, lm = -INFINITY;
   for (int c = tid * 4; c < V; c += SL_NT * 4) {
-    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float4 v = ld_dev4(row + c);
     *reinterpret_cast<float4*>(xs + c) = v;
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -342,11 +363,11 @@ __device__ __forceinline__ void greedy_row(const SmallLoopArgs& p, int b, int t,
     const int word = w.i < 0 ? 0 : w.i;
     const int nfin = (word == p.eos) ? 1 : 0;
     p.hist_scores[o] = w.i < 0 ? -INFINITY : w.s;
-    p.hist_ids[o] = word;
+    st_dev(p.hist_ids + o, word);
     p.hist_parents[o] = 0;
-    p.hist_lp[o] = w.t;
-    p.fin[b] = (uint8_t)nfin;
-    p.len[b] = len + ((word != p.eos && !nfin) ? 1 : 0);
+    st_dev(p.hist_lp + o, w.t);
+    st_dev(p.fin + b, (uint8_t)nfin);
+    st_dev(p.len + b, len + ((word != p.eos && !nfin) ? 1 : 0));
   }
   __syncthreads();  // (whatever runs next in this workgroup reuses the LDS)
 }
@@ -371,7 +392,7 @@ __global__ __launch_bounds__(SL_NT, 1) void small_loop_kernel(SmallLoopArgs p) {
   ICAP_SL_STAMP(1)
   if (!grid_barrier(p, epoch, s_flag)) return;
   ICAP_SL_STAMP(2)
-  if (bid < p.B) attention_body<SL_NT, 1, UCH, true, ATT_ACT_TANH, false>(a, smem, bid, nb);
+  if (bid < p.B) attention_body<SL_NT, 1, UCH, true, ATT_ACT_TANH, true, false, true>(a, smem, bid, nb);
   ICAP_SL_STAMP(3)
   if (!grid_barrier(p, epoch, s_flag)) return;
   ICAP_SL_STAMP(4)
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(SL_NT, 1) void small_loop_kernel(SmallLoopArgs p) {
     for (int b = bid; b < p.B; b += nb) greedy_row(p, b, t, smem);
     if (more) {
       const int rb = nb - 1 - bid;
-      if (rb < p.B) attention_body<SL_NT, 1, UCH, true, ATT_ACT_TANH, false>(a, smem, rb, nb);
+      if (rb < p.B) attention_body<SL_NT, 1, UCH, true, ATT_ACT_TANH, true, false, true>(a, smem, rb, nb);
     }
     ICAP_SL_STAMP(8 + 6 * t + 4)
     if (!grid_barrier(p, epoch, s_flag)) return;
