@@ -1499,15 +1499,32 @@ int launch_dense(const DenseArgs& a, bool vec, hipStream_t s) {
 
 int dense_f32_strided(const float* x, int lda, const float* w, const float* bias, float* y, int M,
                       int K, int N, int act, hipStream_t s);
+static int dense_f32_impl(const float* x, int lda, const float* w, const float* bias, float* y, int M,
+                          int K, int N, int act, bool throughput, hipStream_t s);
 
 int dense_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
               int act, hipStream_t s) {
   return dense_f32_strided(x, K, w, bias, y, M, K, N, act, s);
 }
 
+// dense_f32 for callers whose products come in long runs of equal launches (the transformer
+// stack: six layers of them per position) rather than on a decode step's critical path: where
+// dense_f32 picks a split-K form for its short latency, this one picks the plain tile kernel
+// when that is the faster launch.  The two forms sum in different orders, so a caller sticks to
+// one of the entry points.
+int dense_f32_throughput(const float* x, const float* w, const float* bias, float* y, int M, int K,
+                         int N, int act, hipStream_t s) {
+  return dense_f32_impl(x, K, w, bias, y, M, K, N, act, true, s);
+}
+
 // x rows lda floats apart (lda >= K): e.g. every W-th row of a [B*W,K] matrix with lda = W*K.
 int dense_f32_strided(const float* x, int lda, const float* w, const float* bias, float* y, int M,
                       int K, int N, int act, hipStream_t s) {
+  return dense_f32_impl(x, lda, w, bias, y, M, K, N, act, false, s);
+}
+
+static int dense_f32_impl(const float* x, int lda, const float* w, const float* bias, float* y, int M,
+                          int K, int N, int act, bool throughput, hipStream_t s) {
   ICAP_REQUIRE(x && w && y, "dense_f32: null pointer");
   ICAP_REQUIRE(lda >= K && lda % 4 == K % 4, "dense_f32: bad row stride %d for K = %d", lda, K);
   ICAP_REQUIRE(M > 0 && K > 0 && N > 0, "dense_f32: M, K, N must be positive (got %d, %d, %d)", M,
@@ -1544,6 +1561,19 @@ int dense_f32_strided(const float* x, int lda, const float* w, const float* bias
   // 128x128 tiles (8 waves, 32x64 per wave, 2 workgroups = 4 waves per SIMD) when they
   // fill the chip at least 1.5 times, 64x64 tiles (4 waves) for the small projections.
   const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+  {
+    // just under one round of 128x128 tiles (two per compute unit): half of the units would run
+    // one tile, the other half two - 64x128 tiles fill them evenly ([3072,512] x [512,2048]:
+    // the feed-forward network 16.5 against 18.2 ms per decode of the
+    // 6-layer stack).  Tuning knob ICAP_MID_FORM=0 (128x128) | 1 (64x128) | 2 (64x64).
+    static const char* mid_env = getenv("ICAP_MID_FORM");
+    const int mid = mid_env ? atoi(mid_env) : 1;
+    // (768 tiles, a round and a half: no difference, 90.2 against 90.0 ms of projections per decode)
+    if (mid && vec && K % BK == 0 && big_tiles >= 384 && big_tiles < 512) {
+      if (mid == 1) return launch_dense<64, 128, 2, 4, 2>(a, vec, s);
+      return launch_dense<64, 64, 2, 2, 2>(a, vec, s);
+    }
+  }
   if (big_tiles >= 384) return launch_dense<128, 128, 4, 2, 2>(a, vec, s);
   {
     // few tiles: the split-K form of the 64x64 tile (tuning knob ICAP_SMALL_KS = 1|2|4)
@@ -1554,7 +1584,11 @@ int dense_f32_strided(const float* x, int lda, const float* w, const float* bias
     // main kernel beat the split-K form (93 against 86 TFLOP/s)
     if (vec && K >= 1024 && K % BK == 0 && tiles64 > 128 && tiles64 <= 512 && !ks_env)
       return launch_dense<64, 128, 2, 4, 2>(a, vec, s);
-    if (ks > 1 && vec && K % 64 == 0 && N >= 4 && tiles64 <= 512 &&
+    // (dense_f32_throughput; more 64x64 tiles than compute units and K = 512 or 256: the plain
+    // 64x64 kernel below is ahead of the 1024-thread split-K form - [3072,512] x [512,512],
+    // 384 tiles: 22.8 against 26.4 us per launch)
+    const bool plain64 = throughput && tiles64 > 256 && (K == 512 || K == 256) && !ks_env;
+    if (ks > 1 && !plain64 && vec && K % 64 == 0 && N >= 4 && tiles64 <= 512 &&
         (long long)M * lda < (1LL << 31) && (long long)K * N < (1LL << 31)) {
       a.tiles_m = ceil_div(M, 64);
       a.tiles_n = ceil_div(N, 64);

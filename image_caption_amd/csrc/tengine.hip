@@ -16,6 +16,7 @@
 namespace icap {
 
 int dense_f32(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int dense_f32_throughput(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int dense_topk_half_tiles(int N);
 int dense_topk_record_floats(int top_k);
 bool dense_topk_supported(const float*, const float*, int, int, int, int);
@@ -191,9 +192,9 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     }
     {  // self-attention: query from LayerNorm(x); keys / values from the raw x as written
       TTimed t(e, ICAP_TK_PROJ, s);
-      ICAP_TTRY(dense_f32(e->y, L.self_q_kernel, L.self_q_bias, e->q, N, H, HD, ICAP_ACT_NONE, s));
+      ICAP_TTRY(dense_f32_throughput(e->y, L.self_q_kernel, L.self_q_bias, e->q, N, H, HD, ICAP_ACT_NONE, s));
       float* kv_new = e->kv_self[l] + (size_t)pos * N * 2 * HD;
-      ICAP_TTRY(dense_f32(c.kv_from_normed ? e->y : e->x, e->w_kv_self[l], e->b_kv_self[l], kv_new, N,
+      ICAP_TTRY(dense_f32_throughput(c.kv_from_normed ? e->y : e->x, e->w_kv_self[l], e->b_kv_self[l], kv_new, N,
                           H, 2 * HD, ICAP_ACT_NONE, s));
     }
     {
@@ -202,7 +203,7 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     }
     {
       TTimed t(e, ICAP_TK_PROJ, s);
-      ICAP_TTRY(dense_f32(e->att, L.self_o_kernel, L.self_o_bias, e->o, N, HD, H, ICAP_ACT_NONE, s));
+      ICAP_TTRY(dense_f32_throughput(e->att, L.self_o_kernel, L.self_o_bias, e->o, N, HD, H, ICAP_ACT_NONE, s));
     }
     {
       TTimed t(e, ICAP_TK_LAYERNORM, s);
@@ -210,7 +211,7 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     }
     {
       TTimed t(e, ICAP_TK_PROJ, s);
-      ICAP_TTRY(dense_f32(e->y, L.cross_q_kernel, L.cross_q_bias, e->q, N, H, HD, ICAP_ACT_NONE, s));
+      ICAP_TTRY(dense_f32_throughput(e->y, L.cross_q_kernel, L.cross_q_bias, e->q, N, H, HD, ICAP_ACT_NONE, s));
     }
     {
       TTimed t(e, ICAP_TK_CROSS_ATT, s);
@@ -219,7 +220,7 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     }
     {
       TTimed t(e, ICAP_TK_PROJ, s);
-      ICAP_TTRY(dense_f32(e->att, L.cross_o_kernel, L.cross_o_bias, e->o, N, HD, H, ICAP_ACT_NONE, s));
+      ICAP_TTRY(dense_f32_throughput(e->att, L.cross_o_kernel, L.cross_o_bias, e->o, N, HD, H, ICAP_ACT_NONE, s));
     }
     {
       TTimed t(e, ICAP_TK_LAYERNORM, s);
@@ -227,9 +228,9 @@ int stack_pass(icap_tengine* e, const int32_t* ids, int pos, hipStream_t s) {
     }
     {
       TTimed t(e, ICAP_TK_FFN, s);
-      ICAP_TTRY(dense_f32(e->y, L.ffn_filter_kernel, L.ffn_filter_bias, e->f, N, H, c.filter,
+      ICAP_TTRY(dense_f32_throughput(e->y, L.ffn_filter_kernel, L.ffn_filter_bias, e->f, N, H, c.filter,
                           ICAP_ACT_RELU, s));
-      ICAP_TTRY(dense_f32(e->f, L.ffn_output_kernel, L.ffn_output_bias, e->o, N, c.filter, H,
+      ICAP_TTRY(dense_f32_throughput(e->f, L.ffn_output_kernel, L.ffn_output_bias, e->o, N, c.filter, H,
                           ICAP_ACT_NONE, s));
     }
     pending = e->o;

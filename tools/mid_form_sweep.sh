@@ -1,0 +1,5 @@
+cd "$GRAFT_REPO_ROOT" || exit 1
+run() { echo "== $*"; env "$@" timeout -k 10 200 python bench.py --config transformer_b1024_fp32_conventional --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['kernel_ms_per_step'])" || exit 1; }
+run ICAP_MID_FORM=0
+run ICAP_MID_FORM=1
+run ICAP_MID_FORM=2
